@@ -1,0 +1,205 @@
+/*
+ * fastvision_amd.h -- C ABI of libfastvision_amd.so: the MI355X (gfx950) kernels behind the
+ * YOLOv3 training hot path of ielym/fastvision.
+ *
+ * The reference is pure Python on PyTorch and has NO FFI of its own (SURVEY.md section 8b): the boundary a
+ * maintainer would bind is the set of ATen ops its modules issue.  Each entry point below names the
+ * reference call site it replaces (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes binding the reference side would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller for the
+ *     duration of the call (borrowed from torch.Tensor.data_ptr()); outputs are preallocated;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); nothing here
+ *     synchronises the host, allocates, or copies to the host;
+ *   - every function returns 0 on success, a negative fva_status otherwise; fva_last_error()
+ *     returns a static message for the calling thread;
+ *   - dtype: FVA_F32 (exact fp32, f32-input MFMA) or FVA_BF16 (bf16 storage, fp32 accumulate).
+ *
+ * Activation layout ("halo NHWC"): a feature map of logical shape [B,C,H,W] is stored as
+ * [B][H+2*pad][W+2*pad][C] with a zero border of `pad` pixels (pad is 1 for every map a 3x3 conv or
+ * its dgrad reads, 0 otherwise).  Channels are contiguous.  Raw conv outputs (pre-BN) are dense
+ * [B*OH*OW][Cout] (pad 0).
+ */
+#ifndef FASTVISION_AMD_H
+#define FASTVISION_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { FVA_F32 = 0, FVA_BF16 = 1 } fva_dtype;
+
+typedef enum {
+    FVA_OK = 0,
+    FVA_ERR_ARG = -1,      /* unsupported shape / null pointer / bad enum */
+    FVA_ERR_LAUNCH = -2,   /* hipLaunchKernel or hipGetLastError failed */
+    FVA_ERR_WORKSPACE = -3 /* workspace too small: call the matching *_workspace() */
+} fva_status;
+
+const char* fva_last_error(void);
+int fva_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution (no bias), implicit GEMM on MFMA.  Replaces nn.Conv2d as used by ConvBlock3x3 /
+ * ConvBlock1x1 (classfication/models/darknet53.py:5-9,22-44; detection/neck/yolov3neck.py:5-9,22-44;
+ * demos/yolov3_u/models/{darknet,yolov3}.py:6-40) and its autograd backward.
+ * ksize in {1,3}, padding = ksize/2, stride in {1,2}, groups 1, dilation 1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;   /* fva_dtype of activations and packed weights */
+    int32_t B, H, W; /* logical input size */
+    int32_t Cin, Cout;
+    int32_t ksize, stride;
+    int32_t in_pad;  /* zero border of the input buffer  (>= ksize/2) */
+    int32_t dy_pad;  /* zero border of the dY buffer used by dgrad/wgrad (>= 1 when ksize==3) */
+} fva_conv_desc;
+
+/* fp32 OIHW master weights [Cout][Cin][k][k] -> the two packed operand layouts (dtype of desc):
+ *   w_fwd [k*k (+1 pad tap if Cin==32 && bf16)][Cout][Cin]   and   w_dgrad [k*k (+pad)][Cin][Cout].
+ * Either output may be NULL.  Sizes in elements: fva_conv_packed_elems(). */
+int fva_conv_pack_weights(const fva_conv_desc* d, const float* w_oihw, void* w_fwd, void* w_dgrad, void* stream);
+int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad);
+
+/* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
+ * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
+ * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
+int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
+int32_t fva_conv_stat_blocks(const fva_conv_desc* d);
+
+/* dx[B][H][W][Cin] (dense, dtype) (+)= conv_transpose(dy, w).  dy is halo NHWC with border d->dy_pad. */
+int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate, void* stream);
+
+/* dw (fp32, OIHW) (+)= sum_pixels dy x.  Deterministic: split-K partial tiles go to `workspace`
+ * (fva_conv_wgrad_workspace() bytes) and are reduced in fixed order. */
+int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d);
+
+/* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 4 (darknet53.py:73 `conv0`), direct kernel.
+ * y dense [B*H*W][Cout] dtype + BN partial stats;  wgrad from dy dense [B*H*W][Cout] (pad 0). */
+int fva_stem_fwd(int dtype, const float* images_nchw, const float* w_oihw, void* y, float* stats_partial,
+                 int B, int Cin, int H, int W, int Cout, void* stream);
+int32_t fva_stem_stat_blocks(int B, int H, int W);
+int fva_stem_wgrad(int dtype, const float* images_nchw, const void* dy, float* dw_oihw, int accumulate,
+                   void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
+int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
+
+/* Head: biased 1x1 conv to N = A*(5+C) channels (detection/head/yolov3head.py:50,60;
+ * demos/yolov3_u/models/yolov3.py:119-135).  Output fp32, dense [B*H*W][N] (pixel-major, N contiguous):
+ * the library's permuted [B,A,H,W,5+C] (yolov3head.py:63) and the demo's NCHW are strided views of it. */
+int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream);
+/* dhead fp32 [M][N] * (*grad_scale, device scalar, may be NULL = 1) -> dy dtype [M][Npad] (Npad = N rounded
+ * up to 64, pad columns zero) and dbias[N] (+)= column sums. */
+int fva_head_bwd_prepare(int dtype, const float* dhead, const float* grad_scale, void* dy, float* dbias,
+                         int accumulate, int64_t M, int N, int Npad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (training + eval) fused with SiLU and the residual add.  Replaces nn.BatchNorm2d +
+ * nn.SiLU (+ `identity + conv2`) in ConvBlock*/ResidualBlock (darknet53.py:11-17,28-31,58-62).
+ * ---------------------------------------------------------------------------------------------- */
+/* Reduce conv partial stats -> batch mean / biased var; update running stats (momentum, unbiased var);
+ * emit save_mean, save_rstd and the fused scale = gamma*rstd, shift = beta - mean*scale. */
+int fva_bn_finalize(const float* stats_partial, int32_t nblocks, int64_t count, int32_t C,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* save_mean, float* save_rstd, float* scale, float* shift,
+                    void* stream);
+/* Eval mode: scale/shift from running stats. */
+int fva_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* z = silu(y*scale + shift) (+ residual); writes the whole halo buffer z[B][H+2p][W+2p][C] incl. zero
+ * border.  residual (optional) has the layout of z with border res_pad. */
+int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+                      int res_pad, void* z, int z_pad, int B, int H, int W, int C, void* stream);
+/* Backward, pass 1: partial sums over pixels of dU = dz*silu'(u) and dU*xhat (u = y*scale+shift). */
+int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks,
+                           int64_t M, int C, void* stream);
+int32_t fva_bn_bwd_blocks(int64_t M, int C);
+/* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2. */
+int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
+                        const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
+                        void* stream);
+/* Backward, pass 2: dy = gamma*rstd*(dU - dbeta/n - xhat*dgamma/n) written as halo buffer (border dy_pad). */
+int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_rstd, const float* coef, void* dy, int dy_pad,
+                          int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FPN glue and layout conversion.  Replaces nn.Upsample(scale_factor=2,'nearest') + torch.cat
+ * (yolov3neck.py:71,105,110; demos/yolov3_u/models/yolov3.py:96,100).
+ * ---------------------------------------------------------------------------------------------- */
+/* out[B][2h+2][2w+2][Cup+Cskip] (pad 1).  up: [B][h+2pu][w+2pu][Cup]; skip: [B][2h+2ps][2w+2ps][Cskip].
+ * up_first != 0 -> channel order [up | skip] (library), else [skip | up] (demo). */
+int fva_upsample2_concat_fwd(int dtype, const void* up, int up_pad, const void* skip, int skip_pad, void* out,
+                             int B, int h, int w, int Cup, int Cskip, int up_first, void* stream);
+/* dcat dense [B][2h][2w][Cup+Cskip] -> dup dense [B][h][w][Cup] (2x2 sums) and dskip dense [B][2h][2w][Cskip]. */
+int fva_upsample2_concat_bwd(int dtype, const void* dcat, void* dup, void* dskip, int B, int h, int w, int Cup,
+                             int Cskip, int up_first, void* stream);
+/* Arbitrary-stride fp32/bf16 [B,C,H,W] tensor -> halo NHWC buffer of `dtype` (foreign inputs). */
+int fva_pack_nchw(int dtype, const void* src, int src_is_bf16, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                  void* dst, int dst_pad, int B, int C, int H, int W, void* stream);
+/* Cast / re-layout dense or halo NHWC -> dense NHWC of another dtype (gradient hand-off at the API edge). */
+int fva_cast_nhwc(const void* src, int src_dtype, int src_pad, void* dst, int dst_dtype, int dst_pad,
+                  int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Target assignment + loss, library surface.  Replaces Yolov3Loss.build_target / forward
+ * (loss/yolov3_loss.py:29-124) with BiCrossEntropyLoss (loss/classification_loss.py:42-65),
+ * CIOULoss (loss/iou_loss.py:88-107) and cal_iou/CIOU/DIOU/xyxy_iou (detection/tools/IOU.py).
+ * Head tensors are addressed through explicit element strides so any view works.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* data;          /* fp32 head tensor of this level */
+    float* grad;          /* fp32 gradient buffer with the SAME strides (may be NULL: loss only) */
+    int64_t sb, sa, sy, sx, sk; /* element strides of (batch, anchor, grid_y, grid_x, channel) */
+    int32_t B, A, H, W, K;      /* K = 5 + num_classes */
+    float anchor_w[8], anchor_h[8]; /* PIXEL-unit anchors of this level (A <= 8) */
+    float stride;               /* backbone stride of this level */
+} fva_head_level;
+
+/* Matcher (build_target, yolov3_loss.py:75-124).  targets [T][6] fp32.  Outputs per level, capacity T*A rows
+ * in the reference's row order (target-major, anchor-minor): count[1] i32, b/gx/gy/a/cls i64 [cap],
+ * xywh [cap][4] f32, anc [cap][2] f32.  Integer outputs are bit-exact with the reference. */
+typedef struct {
+    int32_t* count;
+    int64_t *b, *gx, *gy, *a, *cls;
+    float *xywh, *anc;
+} fva_match_out;
+int fva_yolov3_match(const float* targets, int32_t T, const fva_head_level* level, const fva_match_out* out, void* stream);
+
+/* Loss forward + analytic backward for all levels in one call (yolov3_loss.py:29-72).
+ * loss_out[4] = {total, box, conf, cls} (total already * ratios * B); grads (if level.grad != NULL) are
+ * d total / d head, written for EVERY element (zeros included).  workspace: fva_yolov3_loss_workspace(). */
+int fva_yolov3_loss(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels,
+                    float ratio_box, float ratio_conf, float ratio_cls, float* loss_out,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+int64_t fva_yolov3_loss_workspace(int32_t T, const fva_head_level* levels, int32_t nlevels);
+
+/* Demo loss (demos/yolov3_u/utils/lossv3.py:18-119): best-anchor assignment, BCE/MSE/BCE terms, IoU>0.5
+ * ignore mask, masked objectness BCE.  level.anchor_* are FEATURE-scale here and level.stride is unused.
+ * loss_out[5] = {total, xy, wh, cls, conf} (unweighted parts, as the reference prints them). */
+int fva_demo_loss(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels, float* loss_out,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int64_t fva_demo_loss_workspace(int32_t T, const fva_head_level* levels, int32_t nlevels);
+
+/* IoU family on device (detection/tools/IOU.py, BOX.py).  kind: 0 IoU 1 GIoU 2 DIoU 3 CIoU;
+ * mode: 0 xyxy 1 xywh 2 wh; variant: 0 library 1 demo (iou.py centre sums / minus sign).
+ * pairwise: out[N]; batch: out[N][M]. */
+int fva_iou_pairwise(int kind, int mode, int variant, const float* a, const float* b, float* out, int64_t N, float eps, void* stream);
+int fva_iou_batch(int kind, int mode, int variant, const float* a, const float* b, float* out, int64_t N, int64_t M, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam semantics (demos/yolov3_u/train.py:68), multi-tensor.
+ * ptrs: device array [4][n] of {param, grad, exp_avg, exp_avg_sq} fp32 pointers; sizes: device int64[n].
+ * step is the 1-based step count; lr/betas/eps/weight_decay as torch (L2-in-gradient decay).
+ * ---------------------------------------------------------------------------------------------- */
+int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTVISION_AMD_H */

@@ -1,0 +1,407 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).  The reference is
+imported in place behind the four harness shims SURVEY.md section 8c documents (package-name symlink in
+/tmp, stub modules for the absent torchvision/cv2, the never-defined ``offset`` helper, the torch>=2
+integer ``clamp_`` bound).  No reference source is copied: the fixtures are inputs and outputs only.
+
+    python oracle/make_golden.py lib      # library surface  (fastvision.*)
+    python oracle/make_golden.py demo     # demo surface     (demos/yolov3_u)   -- separate process: its
+                                          # top-level ``utils``/``models`` names clash with nothing else then
+    python oracle/make_golden.py all      # both, as two child processes
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import os
+import subprocess
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, 'tests', 'golden')
+REF = '/root/reference'
+BOOT = '/tmp/fvoracle'
+sys.dont_write_bytecode = True
+warnings.filterwarnings('ignore')
+
+
+def _stub_missing():
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return 0
+    for n in ('torchvision', 'torchvision.ops', 'torchvision.transforms', 'cv2'):
+        sys.modules[n] = _Any(n)
+
+
+def _patch_clamp():
+    import torch
+    orig = torch.Tensor.clamp_
+
+    def clamp_(self, min=None, max=None):
+        if not self.is_floating_point():
+            if isinstance(min, torch.Tensor) and min.dim() == 0:
+                min = int(min.item())
+            if isinstance(max, torch.Tensor) and max.dim() == 0:
+                max = int(max.item())
+        return orig(self, min, max)
+    torch.Tensor.clamp_ = clamp_
+
+
+def boot_lib():
+    os.makedirs(BOOT, exist_ok=True)
+    link = os.path.join(BOOT, 'fastvision')
+    if not os.path.islink(link):
+        os.symlink(REF, link)
+    sys.path.insert(0, BOOT)
+    _stub_missing()
+    _patch_clamp()
+    import fastvision.detection.tools as T
+    T.offset = lambda h, w, mode='xy': T.grid(h, w, mode=mode, dtype='numpy')
+    return T
+
+
+def boot_demo():
+    _stub_missing()
+    _patch_clamp()
+    sys.path.insert(0, os.path.join(REF, 'demos', 'yolov3_u'))
+
+
+sys.path.insert(0, REPO)
+from fastvision_amd.synthetic import synthetic_batch, coco_anchors_px, coco_anchors_feature  # noqa: E402
+
+
+def rand_targets(gen, T, batch):
+    """[T,6] targets incl. awkward ones: tiny/huge boxes, centres on cell borders and at 0 / just below 1."""
+    import torch
+    if T == 0:
+        return torch.zeros(0, 6)
+    b = torch.randint(0, batch, (T,), generator=gen).sort()[0].float()
+    cls = torch.randint(0, 80, (T,), generator=gen).float()
+    wh = torch.exp(np.log(0.005) + (np.log(0.99) - np.log(0.005)) * torch.rand(T, 2, generator=gen))
+    xy = torch.rand(T, 2, generator=gen)
+    if T >= 7:
+        xy[0] = torch.tensor([0.0, 0.0])
+        xy[1] = torch.tensor([0.999999, 0.999999])
+        xy[2] = torch.tensor([0.5, 0.25])          # exactly on cell borders for every grid used
+        xy[3] = torch.tensor([1.0, 1.0])           # needs the clamp (library) -- not used with the demo
+        wh[4] = torch.tensor([1.0, 1.0])
+        wh[5] = torch.tensor([0.001, 0.9])
+    return torch.cat([b.view(-1, 1), cls.view(-1, 1), xy, wh], dim=1)
+
+
+def stats(t):
+    t = t.detach().double().flatten()
+    return np.array([t.sum().item(), t.abs().sum().item()] + t[:4].tolist() + [0.0] * max(0, 4 - t.numel()))
+
+
+# ====================================================================================== library surface
+def gen_lib():
+    import torch
+    T = boot_lib()
+    from fastvision.classfication.models.darknet53 import darknet53, ConvBlock3x3, ConvBlock1x1, ResidualBlock
+    from fastvision.detection.neck.yolov3neck import yolov3neck, UpSampling
+    from fastvision.detection.head.yolov3head import yolov3head
+    from fastvision.detection.models.yolov3 import yolov3
+    from fastvision.loss.yolov3_loss import Yolov3Loss
+    from fastvision.loss.iou_loss import CIOULoss
+    from fastvision.loss.classification_loss import BiCrossEntropyLoss
+
+    def build(seed, training=True):
+        torch.manual_seed(seed)
+        m = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(),
+                   num_anchors_per_level=[3, 3, 3], in_channels=3, num_classes=80, training=training)
+        m.train(training)
+        return m
+
+    out = {}
+    # ---- G1: matcher (build_target) -------------------------------------------------------------------
+    net = build(0)
+    crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+    case = 0
+    for grids in ((13, 26, 52), (20, 40, 80), (2, 4, 8)):
+        for T_ in (0, 1, 7, 64, 234):
+            for seed in range(3):
+                g = torch.Generator().manual_seed(1000 * seed + T_)
+                tg = rand_targets(g, T_, 8)
+                shapes = [torch.zeros(8, 3, s, s, 1) for s in grids]
+                locs, cats, xywh, anc = crit.build_target(shapes, tg)
+                out[f'g1_{case}_grids'] = np.array(grids)
+                out[f'g1_{case}_targets'] = tg.numpy()
+                for l in range(3):
+                    out[f'g1_{case}_l{l}_b'] = locs[l][0].numpy()
+                    out[f'g1_{case}_l{l}_gxy'] = locs[l][1].numpy()
+                    out[f'g1_{case}_l{l}_a'] = locs[l][2].numpy()
+                    out[f'g1_{case}_l{l}_cls'] = cats[l].numpy()
+                    out[f'g1_{case}_l{l}_xywh'] = xywh[l].numpy()
+                    out[f'g1_{case}_l{l}_anc'] = anc[l].numpy()
+                case += 1
+    out['g1_cases'] = np.array(case)
+    # non-square grid (H != W): the [W,H,W,H] scale and the x/y clamp bounds differ
+    g = torch.Generator().manual_seed(77)
+    tg = rand_targets(g, 64, 2)
+    shapes = [torch.zeros(2, 3, 20, 15, 1), torch.zeros(2, 3, 40, 30, 1), torch.zeros(2, 3, 80, 60, 1)]
+    locs, cats, xywh, anc = crit.build_target(shapes, tg)
+    out['g1ns_targets'] = tg.numpy()
+    for l in range(3):
+        out[f'g1ns_l{l}_b'], out[f'g1ns_l{l}_gxy'], out[f'g1ns_l{l}_a'] = [x.numpy() for x in locs[l]]
+        out[f'g1ns_l{l}_cls'], out[f'g1ns_l{l}_xywh'], out[f'g1ns_l{l}_anc'] = cats[l].numpy(), xywh[l].numpy(), anc[l].numpy()
+
+    # ---- G2: IoU family known answers ----------------------------------------------------------------
+    g = torch.Generator().manual_seed(2)
+    n = 256
+    a = torch.rand(n, 4, generator=g) * 10
+    b = torch.rand(n, 4, generator=g) * 10
+    a[:, 2:] = a[:, :2] + torch.rand(n, 2, generator=g) * 8      # valid xyxy
+    b[:, 2:] = b[:, :2] + torch.rand(n, 2, generator=g) * 8
+    edge_a = torch.tensor([[0, 0, 2, 2], [0, 0, 1, 1], [0, 0, 1, 1], [1, 1, 1, 1], [0, 0, 4, 4], [0, 0, 2, 2.]])
+    edge_b = torch.tensor([[0, 0, 2, 2], [2, 2, 3, 3], [1, 0, 2, 1], [1, 1, 1, 1], [1, 1, 2, 2], [0, 0, 2, 4.]])
+    a, b = torch.cat([a, edge_a]), torch.cat([b, edge_b])
+    wa = torch.cat([a[:, 2:] - a[:, :2]])
+    wb = torch.cat([b[:, 2:] - b[:, :2]])
+    xa, xb = T.xyxy2xywh(a), T.xyxy2xywh(b)
+    out['g2_a'], out['g2_b'] = a.numpy(), b.numpy()
+    out['g2_xyxy_iou'] = T.xyxy_iou(a, b).numpy()
+    out['g2_xywh_iou'] = T.xywh_iou(xa, xb).numpy()
+    out['g2_wh_iou'] = T.wh_iou(wa, wb).numpy()
+    out['g2_xyxy_iou_batch'] = T.xyxy_iou_batch(a[:40], b[:24]).numpy()
+    out['g2_xywh_iou_batch'] = T.xywh_iou_batch(xa[:40], xb[:24]).numpy()
+    out['g2_wh_iou_batch'] = T.wh_iou_batch(wa[:40], wb[:24]).numpy()
+    out['g2_giou'] = T.GIOU(a, b).numpy()
+    out['g2_diou'] = T.DIOU(a, b).numpy()
+    out['g2_ciou'] = T.CIOU(a, b).numpy()
+    out['g2_ciou_xywh'] = T.CIOU(xa, xb, mode='xywh').numpy()
+    out['g2_xywh2xyxy'] = T.xywh2xyxy(xa).numpy()
+    out['g2_xyxy2xywhn'] = T.xyxy2xywhn(a, 480, 640).numpy()
+    out['g2_grid_xy'] = T.grid(3, 5, mode='xy').numpy()
+    out['g2_grid_yx'] = T.grid(3, 5, mode='yx').numpy()
+    ar = a.clone().requires_grad_(True)
+    out['g2_cioul'] = CIOULoss('mean')(ar, b).detach().numpy().reshape(1)
+    CIOULoss('mean')(ar, b).backward()
+    out['g2_cioul_grad'] = ar.grad.numpy()
+    p = torch.rand(12, 5, generator=g)
+    lab = torch.randint(0, 5, (12,), generator=g)
+    out['g2_bce_p'], out['g2_bce_lab'] = p.numpy(), lab.numpy()
+    out['g2_bce_mean'] = BiCrossEntropyLoss('mean')(p, lab, already_sigmoid=True).numpy().reshape(1)
+    out['g2_bce_logits_sum'] = BiCrossEntropyLoss('sum')(p * 4 - 2, lab).numpy().reshape(1)
+
+    # ---- G3: Yolov3Loss value + d loss / d head_out --------------------------------------------------
+    def run_loss(tag, tg, grids, batch, seed, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        heads = [(torch.randn(batch, 3, s, s, 85, generator=g) * scale).requires_grad_(True) for s in grids]
+        loss = crit(heads, tg)
+        loss.backward()
+        out[f'g3_{tag}_targets'] = tg.numpy()
+        out[f'g3_{tag}_grids'] = np.array(grids)
+        out[f'g3_{tag}_loss'] = loss.detach().numpy()
+        for l, h in enumerate(heads):
+            out[f'g3_{tag}_head{l}'] = h.detach().numpy()
+            out[f'g3_{tag}_grad{l}'] = h.grad.numpy()
+
+    g = torch.Generator().manual_seed(5)
+    run_loss('rand', rand_targets(g, 9, 2), (2, 4, 8), 2, 11)
+    run_loss('empty', torch.zeros(0, 6), (2, 4, 8), 2, 12)
+    dup = torch.tensor([[0, 3, 0.30, 0.30, 0.20, 0.25], [0, 5, 0.31, 0.32, 0.22, 0.24],
+                        [1, 7, 0.70, 0.60, 0.50, 0.45], [1, 7, 0.72, 0.61, 0.45, 0.50],
+                        [1, 9, 0.10, 0.90, 0.05, 0.06]])
+    run_loss('dup', dup, (2, 4, 8), 2, 13, scale=2.0)
+    _, tg = synthetic_batch(4, 128)
+    run_loss('syn', tg, (4, 8, 16), 4, 14)
+
+    # ---- G4: block-level conv/BN/SiLU fixtures --------------------------------------------------------
+    def run_block(tag, mod, x, extra=None):
+        mod.train()
+        x = x.clone().requires_grad_(True)
+        y = mod(x) if extra is None else extra(mod, x)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(99))
+        (y * gy).sum().backward()
+        out[f'g4_{tag}_x'], out[f'g4_{tag}_y'], out[f'g4_{tag}_gy'] = x.detach().numpy(), y.detach().numpy(), gy.numpy()
+        out[f'g4_{tag}_dx'] = x.grad.numpy()
+        for k, v in mod.state_dict().items():
+            out[f'g4_{tag}_sd_{k}'] = v.numpy()
+        for k, v in mod.named_parameters():
+            out[f'g4_{tag}_gr_{k}'] = v.grad.numpy()
+
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(41); m = ConvBlock3x3(32, 64)
+    out['g4_cb3_w0'] = m.conv.weight.detach().numpy().copy()
+    run_block('cb3', m, torch.randn(2, 32, 10, 12, generator=g))
+    torch.manual_seed(42); m = ConvBlock3x3(32, 64, stride=(2, 2))
+    out['g4_cb3s2_w0'] = m.conv.weight.detach().numpy().copy()
+    run_block('cb3s2', m, torch.randn(2, 32, 10, 12, generator=g))
+    torch.manual_seed(43); m = ConvBlock1x1(64, 32)
+    out['g4_cb1_w0'] = m.conv.weight.detach().numpy().copy()
+    run_block('cb1', m, torch.randn(2, 64, 6, 6, generator=g))
+    torch.manual_seed(44); m = ResidualBlock(64, 32)
+    out['g4_res_w1'] = m.conv1.conv.weight.detach().numpy().copy()
+    out['g4_res_w2'] = m.conv2.conv.weight.detach().numpy().copy()
+    run_block('res', m, torch.randn(2, 64, 8, 8, generator=g))
+    torch.manual_seed(45); m = UpSampling(64, 32)
+    out['g4_up_w0'] = m.squeeze.conv.weight.detach().numpy().copy()
+    skip = torch.randn(2, 32, 8, 8, generator=g)
+    out['g4_up_skip'] = skip.numpy()
+    run_block('up', m, torch.randn(2, 64, 4, 4, generator=g), extra=lambda mod, x: torch.cat([mod(x), skip], dim=1))
+
+    # ---- G5: whole model: init checksums, head outputs, grads and BN buffers after one step ----------
+    seed = 20220504
+    net = build(seed)
+    sd = net.state_dict()
+    out['g5_keys'] = np.array(list(sd.keys()))
+    out['g5_init'] = np.stack([stats(v.float()) for v in sd.values()])
+    images, tg = synthetic_batch(2, 64)
+    out['g5_targets'] = tg.numpy()
+    crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+    pred = net(images)
+    loss = crit(pred, tg)
+    loss.backward()
+    out['g5_loss'] = loss.detach().numpy()
+    for l, h in enumerate(pred):
+        out[f'g5_head{l}'] = h.detach().numpy()
+    out['g5_gradkeys'] = np.array([k for k, _ in net.named_parameters()])
+    out['g5_grads'] = np.stack([stats(p.grad) for _, p in net.named_parameters()])
+    out['g5_after'] = np.stack([stats(v.float()) for v in net.state_dict().values()])
+    # eval-branch decode (inferred ``offset``, App. B-14)
+    net.eval()
+    with torch.no_grad():
+        _, dec = net(images, val=True)
+    out['g5_decode'] = dec.numpy()
+
+    # ---- G6: 100-step loss curve, fixed synthetic batch, B=2 S=128, Adam(1e-4) ------------------------
+    if os.environ.get('GOLDEN_SKIP_CURVE') != '1':
+        net = build(seed)
+        crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+        images, tg = synthetic_batch(2, 128)
+        curve = []
+        for _ in range(100):
+            pred = net(images)
+            opt.zero_grad()
+            loss = crit(pred, tg)
+            loss.backward()
+            opt.step()
+            curve.append(loss.item())
+        out['g6_curve'] = np.array(curve)
+    np.savez_compressed(os.path.join(GOLD, 'lib.npz'), **out)
+    print('lib fixtures:', len(out), 'arrays')
+
+
+# ====================================================================================== demo surface
+def gen_demo():
+    import torch
+    boot_demo()
+    from models.yolov3 import YoloV3
+    from utils.lossv3 import ComputeLoss
+    import utils.iou as DI
+    import builtins
+    out = {}
+    anchors = coco_anchors_feature()
+
+    def build(seed):
+        torch.manual_seed(seed)
+        m = YoloV3(in_channels=3, num_classes=80, anchors=anchors)
+        m.train()
+        return m
+
+    class _Shell:                      # ComputeLoss only reads model.anchors
+        pass
+    shell = _Shell()
+    shell.anchors = anchors
+    crit = ComputeLoss()
+    real_print = builtins.print
+    captured = []
+
+    def quiet(*a, **k):                # the loss prints its four partial losses (lossv3.py:108): capture them
+        captured.append(a)
+
+    def run_loss(tag, tg, grids, batch, seed, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        heads = [(torch.randn(batch, 255, s, s, generator=g) * scale).requires_grad_(True) for s in grids]
+        builtins.print = quiet
+        try:
+            loss = crit(heads, tg, shell)
+        finally:
+            builtins.print = real_print
+        loss.backward()
+        out[f'g3_{tag}_targets'], out[f'g3_{tag}_grids'] = tg.numpy(), np.array(grids)
+        out[f'g3_{tag}_loss'] = loss.detach().numpy()
+        out[f'g3_{tag}_parts'] = np.array(captured[-1], dtype=np.float64)
+        for l, h in enumerate(heads):
+            out[f'g3_{tag}_head{l}'] = h.detach().numpy()
+            out[f'g3_{tag}_grad{l}'] = h.grad.numpy()
+
+    _, tg = synthetic_batch(2, 64)
+    run_loss('syn', tg, (2, 4, 8), 2, 21)
+    _, tg = synthetic_batch(4, 128, seed=99)
+    run_loss('syn4', tg, (4, 8, 16), 4, 22, scale=2.0)
+    dup = torch.tensor([[0, 3, 0.30, 0.30, 0.20, 0.25], [0, 5, 0.31, 0.32, 0.22, 0.24],
+                        [1, 7, 0.70, 0.60, 0.50, 0.45], [1, 7, 0.72, 0.61, 0.45, 0.50]])
+    run_loss('dup', dup, (2, 4, 8), 2, 23)
+
+    # demo IoU variants (centre sums, minus sign) -- demos/yolov3_u/utils/iou.py
+    g = torch.Generator().manual_seed(2)
+    a = torch.rand(64, 4, generator=g) * 10
+    b = torch.rand(64, 4, generator=g) * 10
+    a[:, 2:] = a[:, :2] + torch.rand(64, 2, generator=g) * 8
+    b[:, 2:] = b[:, :2] + torch.rand(64, 2, generator=g) * 8
+    out['g2_a'], out['g2_b'] = a.numpy(), b.numpy()
+    out['g2_diou'] = DI.DIOU(a, b).numpy()
+    out['g2_ciou'] = DI.CIOU(a, b).numpy()
+
+    # whole model
+    seed = 20220504
+    net = build(seed)
+    sd = net.state_dict()
+    out['g5_keys'] = np.array(list(sd.keys()))
+    out['g5_init'] = np.stack([stats(v.float()) for v in sd.values()])
+    images, tg = synthetic_batch(2, 64)
+    pred = net(images)
+    builtins.print = quiet
+    try:
+        loss = crit(pred, tg, net)
+    finally:
+        builtins.print = real_print
+    loss.backward()
+    out['g5_loss'] = loss.detach().numpy()
+    for l, h in enumerate(pred):
+        out[f'g5_head{l}'] = h.detach().numpy()
+    out['g5_gradkeys'] = np.array([k for k, _ in net.named_parameters()])
+    out['g5_grads'] = np.stack([stats(p.grad) for _, p in net.named_parameters()])
+    out['g5_after'] = np.stack([stats(v.float()) for v in net.state_dict().values()])
+
+    if os.environ.get('GOLDEN_SKIP_CURVE') != '1':
+        net = build(seed)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+        images, tg = synthetic_batch(2, 128)
+        curve = []
+        builtins.print = quiet
+        try:
+            for _ in range(100):
+                pred = net(images)
+                opt.zero_grad()
+                loss = crit(pred, tg, net)
+                loss.backward()
+                opt.step()
+                curve.append(loss.item())
+        finally:
+            builtins.print = real_print
+        out['g6_curve'] = np.array(curve)
+    np.savez_compressed(os.path.join(GOLD, 'demo.npz'), **out)
+    print('demo fixtures:', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    os.makedirs(GOLD, exist_ok=True)
+    if which == 'lib':
+        gen_lib()
+    elif which == 'demo':
+        gen_demo()
+    else:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+        for s in ('lib', 'demo'):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), s], env=env)

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def gold_lib():
+    return np.load(os.path.join(GOLD, 'lib.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def gold_demo():
+    return np.load(os.path.join(GOLD, 'demo.npz'), allow_pickle=False)
