@@ -1,0 +1,19 @@
+"""fastvision_amd -- the YOLOv3 detection training hot path of ielym/fastvision on MI355X (gfx950).
+
+The package mirrors the reference's Python surface for that path and nothing else:
+
+    fastvision_amd.classfication.models.darknet53          (classfication/models/darknet53.py)
+    fastvision_amd.detection.neck / .head / .models        (detection/{neck,head,models})
+    fastvision_amd.detection.tools                         (IOU.py, BOX.py, GRID.py)
+    fastvision_amd.loss                                    (yolov3_loss.py, iou_loss.py, classification_loss.py)
+    fastvision_amd.utils.Fit                               (utils/fit.py step contract)
+    fastvision_amd.demos.yolov3_u.{models,utils,cfg}       (demos/yolov3_u: YoloV3, ComputeLoss, Fit/_Train)
+
+plus ``FusedAdam`` and ``parallel`` (one process per GPU, RCCL gradient all-reduce).  All device arithmetic
+runs in hand-written HIP kernels behind the C ABI of include/fastvision_amd.h (csrc/); importing the package
+is cheap, the shared library is loaded on first use and its absence is an error (no CPU fallback).
+"""
+from .ops import compute_dtype, get_compute_dtype, set_compute_dtype  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
+
+__version__ = '0.1.0'

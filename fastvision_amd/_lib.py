@@ -1,0 +1,100 @@
+"""ctypes binding of libfastvision_amd.so (include/fastvision_amd.h).  Fails loudly: no CPU fallback.
+
+The library is built in-tree by ``python fastvision_amd/csrc/build.py`` (or ``__graft_entry__.build()``).
+Every wrapper raises ``RuntimeError`` with ``fva_last_error()`` when the C call returns non-zero.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libfastvision_amd.so')
+
+F32, BF16 = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('dtype', 'B', 'H', 'W', 'Cin', 'Cout', 'ksize', 'stride', 'in_pad', 'dy_pad')]
+
+
+class HeadLevel(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('grad', C.c_void_p),
+                ('sb', C.c_int64), ('sa', C.c_int64), ('sy', C.c_int64), ('sx', C.c_int64), ('sk', C.c_int64),
+                ('B', C.c_int32), ('A', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('K', C.c_int32),
+                ('anchor_w', C.c_float * 8), ('anchor_h', C.c_float * 8), ('stride', C.c_float)]
+
+
+class MatchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_D = C.POINTER(ConvDesc)
+_H = C.POINTER(HeadLevel)
+
+# name -> (restype, argtypes); status-returning functions have restype int and are checked
+PROTOTYPES = {
+    'fva_last_error': (C.c_char_p, []),
+    'fva_version': (_I, []),
+    'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
+    'fva_conv_packed_elems': (_L, [_D, _I]),
+    'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv_stat_blocks': (_I, [_D]),
+    'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _L, _P]),
+    'fva_conv_wgrad_workspace': (_L, [_D]),
+    'fva_stem_fwd': (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'fva_stem_stat_blocks': (_I, [_I, _I, _I]),
+    'fva_stem_wgrad': (_I, [_I, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    'fva_stem_wgrad_workspace': (_L, [_I, _I, _I, _I, _I]),
+    'fva_head_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_head_bwd_prepare': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'fva_bn_finalize': (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    'fva_bn_eval_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    'fva_bn_silu_apply': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'fva_bn_silu_bwd_reduce': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
+    'fva_bn_bwd_blocks': (_I, [_I, _L, _I]),
+    'fva_bn_bwd_finalize': (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P]),
+    'fva_bn_silu_bwd_apply': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'fva_upsample2_concat_fwd': (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'fva_upsample2_concat_bwd': (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'fva_pack_nchw': (_I, [_I, _P, _I, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _P]),
+    'fva_cast_nhwc': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'fva_yolov3_match': (_I, [_P, _I, _H, C.POINTER(MatchOut), _P]),
+    'fva_yolov3_loss': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _P, _L, _P]),
+    'fva_yolov3_loss_workspace': (_L, [_I, _H, _I]),
+    'fva_demo_loss': (_I, [_P, _I, _H, _I, _P, _P, _L, _P]),
+    'fva_demo_loss_workspace': (_L, [_I, _H, _I]),
+    'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),
+    'fva_iou_batch': (_I, [_I, _I, _I, _P, _P, _P, _L, _L, _F, _P]),
+    'fva_adam_step': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
+}
+UNCHECKED = {'fva_last_error', 'fva_version', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+             'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_bn_bwd_blocks', 'fva_yolov3_loss_workspace',
+             'fva_demo_loss_workspace'}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes.  Raises if it is missing: build it first."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'fastvision_amd: {LIB_PATH} is missing -- the HIP extension is REQUIRED (no CPU fallback). '
+                           'Build it with `python fastvision_amd/csrc/build.py`.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call a status-returning entry point; raise RuntimeError(fva_last_error()) on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name not in UNCHECKED and rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib.fva_last_error().decode()}')
+    return rc

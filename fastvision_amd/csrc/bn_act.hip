@@ -1,0 +1,535 @@
+// BatchNorm2d (train/eval) + SiLU (+ residual add) forward and backward, and the FPN upsample/concat and
+// layout helpers, for gfx950.  All of these are HBM-bound streaming kernels: 16 bytes per lane, channels
+// contiguous (NHWC), no LDS except for the per-block channel reductions.
+//
+// Algorithmic bytes per element (bf16): apply = 2 (y) + 2 (z) [+2 residual]; backward pass 1 = 4 (dz, y);
+// backward pass 2 = 4 + 2 (dy).
+//
+// Replaces nn.BatchNorm2d / nn.SiLU / `identity + conv2` (reference classfication/models/darknet53.py:11-17,
+// 28-31, 58-62) and nn.Upsample + torch.cat (detection/neck/yolov3neck.py:71,105,110).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float u) { return u * sigmoidf_(u); }
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = sigmoidf_(u);
+    return s * (1.f + u * (1.f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward statistics -> coefficients.  Block = 16 channels x 16 partial-row groups.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, int64_t* nbt,
+                                                          float momentum, float eps, float* save_mean, float* save_rstd,
+                                                          float* scale, float* shift) {
+    __shared__ double red[2][16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = ry; b < nblocks; b += 16) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        s1 = s2 = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            s1 += red[0][k][cx];
+            s2 += red[1][k][cx];
+        }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[c], bt = beta[c];
+        save_mean[c] = (float)mean;
+        save_rstd[c] = rstd;
+        const float sc = g * rstd;
+        scale[c] = sc;
+        shift[c] = bt - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+struct HaloIdx {
+    int B, H, W, C, pad, Hp, Wp, cpp;  // cpp = 16-B chunks per pixel
+    FastDiv div_cpp, div_wp, div_img;
+    int64_t total;  // chunks over the padded buffer
+};
+HaloIdx make_halo(int B, int H, int W, int C, int pad, int epc) {
+    HaloIdx h;
+    h.B = B; h.H = H; h.W = W; h.C = C; h.pad = pad;
+    h.Hp = H + 2 * pad; h.Wp = W + 2 * pad; h.cpp = C / epc;
+    h.div_cpp = make_fastdiv(h.cpp);
+    h.div_wp = make_fastdiv(h.Wp);
+    h.div_img = make_fastdiv(h.Hp * h.Wp);
+    h.total = (int64_t)B * h.Hp * h.Wp * h.cpp;
+    return h;
+}
+// decode a chunk index of the padded buffer; returns false on the zero border
+__device__ __forceinline__ bool halo_decode(const HaloIdx& h, uint32_t idx, int& b, int& y, int& x, int& cc) {
+    const uint32_t pix = fd_div(idx, h.div_cpp);
+    cc = idx - pix * h.cpp;
+    b = fd_div(pix, h.div_img);
+    const uint32_t rem = pix - (uint32_t)b * (h.Hp * h.Wp);
+    const uint32_t yp = fd_div(rem, h.div_wp);
+    const uint32_t xp = rem - yp * h.Wp;
+    y = (int)yp - h.pad;
+    x = (int)xp - h.pad;
+    return y >= 0 && y < h.H && x >= 0 && x < h.W;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const T* __restrict__ res,
+                                                            int res_pad, T* __restrict__ z, const HaloIdx h) {
+    constexpr int EPC = Vec16<T>::N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < h.total; i += (int64_t)gridDim.x * blockDim.x) {
+        int b, yy, xx, cc;
+        Vec16<T> out;
+        if (halo_decode(h, (uint32_t)i, b, yy, xx, cc)) {
+            const int64_t m = ((int64_t)b * h.H + yy) * h.W + xx;
+            const Vec16<T> v = *(const Vec16<T>*)(y + m * h.C + cc * EPC);
+            Vec16<T> r;
+            if (res) {
+                const int rW = h.W + 2 * res_pad;
+                const int64_t rp = ((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + xx + res_pad;
+                r = *(const Vec16<T>*)(res + rp * h.C + cc * EPC);
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cc * EPC + e;
+                float o = silu_f(v.get(e) * scale[c] + shift[c]);
+                if (res) o += r.get(e);
+                out.set(e, o);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
+        }
+        *(Vec16<T>*)(z + i * EPC) = out;
+    }
+}
+
+// backward pass 1: per-channel partial sums of dU and dU*xhat.  threads = (channel chunk, pixel row group)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ part, int64_t M, int C, int rows_per_block) {
+    constexpr int EPC = Vec16<T>::N;
+    extern __shared__ float red[];  // [2][rpi][C]
+    const int cpp = C / EPC, rpi = 256 / cpp;
+    const int cx = threadIdx.x % cpp, py = threadIdx.x / cpp;
+    float sc[EPC], sh[EPC], mu[EPC], rs[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cx * EPC + e;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c];
+        s1[e] = s2[e] = 0.f;
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t m1 = m0 + rows_per_block;
+    if (m1 > M) m1 = M;
+    for (int64_t m = m0 + py; m < m1; m += rpi) {
+        const Vec16<T> g = *(const Vec16<T>*)(dz + m * C + cx * EPC);
+        const Vec16<T> v = *(const Vec16<T>*)(y + m * C + cx * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float yv = v.get(e);
+            const float du = g.get(e) * silu_grad(yv * sc[e] + sh[e]);
+            s1[e] += du;
+            s2[e] += du * (yv - mu[e]) * rs[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[(0 * rpi + py) * C + cx * EPC + e] = s1[e];
+        red[(1 * rpi + py) * C + cx * EPC + e] = s2[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        float s = 0.f;
+        for (int k = 0; k < rpi; ++k) s += red[(which * rpi + k) * C + c];
+        part[((int64_t)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                              float* dgamma, float* dbeta, int accumulate, float* coef) {
+    __shared__ double red[2][16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = ry; b < nblocks; b += 16) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        s1 = s2 = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            s1 += red[0][k][cx];
+            s2 += red[1][k][cx];
+        }
+        const float db = (float)s1, dg = (float)s2;
+        dbeta[c] = accumulate ? dbeta[c] + db : db;
+        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+        const float a = gamma[c] * rstd[c];
+        coef[c] = a;
+        coef[C + c] = (float)(-(double)a * s2 / count);
+        coef[2 * C + c] = (float)(-(double)a * s1 / count);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h) {
+    constexpr int EPC = Vec16<T>::N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < h.total; i += (int64_t)gridDim.x * blockDim.x) {
+        int b, yy, xx, cc;
+        Vec16<T> out;
+        if (halo_decode(h, (uint32_t)i, b, yy, xx, cc)) {
+            const int64_t m = ((int64_t)b * h.H + yy) * h.W + xx;
+            const Vec16<T> g = *(const Vec16<T>*)(dz + m * h.C + cc * EPC);
+            const Vec16<T> v = *(const Vec16<T>*)(y + m * h.C + cc * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cc * EPC + e;
+                const float yv = v.get(e);
+                const float du = g.get(e) * silu_grad(yv * scale[c] + shift[c]);
+                const float xh = (yv - mean[c]) * rstd[c];
+                out.set(e, coef[c] * du + coef[h.C + c] * xh + coef[2 * h.C + c]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
+        }
+        *(Vec16<T>*)(dy + i * EPC) = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nearest x2 upsample + channel concat into a halo buffer (pad 1)
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ up, int up_pad, const T* __restrict__ skip,
+                                                        int skip_pad, T* __restrict__ out, const HaloIdx h, int hh, int ww,
+                                                        int Cup, int Cskip, int up_first) {
+    constexpr int EPC = Vec16<T>::N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < h.total; i += (int64_t)gridDim.x * blockDim.x) {
+        int b, yy, xx, cc;
+        Vec16<T> v;
+        if (halo_decode(h, (uint32_t)i, b, yy, xx, cc)) {
+            int c = cc * EPC;
+            const bool from_up = up_first ? (c < Cup) : (c >= Cskip);
+            if (from_up) {
+                if (!up_first) c -= Cskip;
+                const int64_t pix = ((int64_t)b * (hh + 2 * up_pad) + (yy >> 1) + up_pad) * (ww + 2 * up_pad) + (xx >> 1) + up_pad;
+                v = *(const Vec16<T>*)(up + pix * Cup + c);
+            } else {
+                if (up_first) c -= Cup;
+                const int64_t pix = ((int64_t)b * (2 * hh + 2 * skip_pad) + yy + skip_pad) * (2 * ww + 2 * skip_pad) + xx + skip_pad;
+                v = *(const Vec16<T>*)(skip + pix * Cskip + c);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v.set(e, 0.f);
+        }
+        *(Vec16<T>*)(out + i * EPC) = v;
+    }
+}
+
+// dcat dense [B][2h][2w][Ct] -> dup dense [B][h][w][Cup] (sum of the 2x2 block) and dskip dense [B][2h][2w][Cskip]
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dcat, T* __restrict__ dup, T* __restrict__ dskip,
+                                                        int B, int hh, int ww, int Cup, int Cskip, int up_first) {
+    constexpr int EPC = Vec16<T>::N;
+    const int Ct = Cup + Cskip, cu = Cup / EPC, cs = Cskip / EPC;
+    const int64_t n_up = (int64_t)B * hh * ww * cu, n_sk = (int64_t)B * 4 * hh * ww * cs;
+    const int uoff = up_first ? 0 : Cskip, soff = up_first ? Cup : 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_up + n_sk; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_up) {
+            const int cc = (int)(i % cu);
+            const int64_t pix = i / cu;
+            const int x = (int)(pix % ww), y = (int)((pix / ww) % hh), b = (int)(pix / ((int64_t)ww * hh));
+            float acc[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int64_t sp = ((int64_t)b * 2 * hh + 2 * y + dy) * (2 * ww) + 2 * x + dx;
+                    const Vec16<T> v = *(const Vec16<T>*)(dcat + sp * Ct + uoff + cc * EPC);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[e] += v.get(e);
+                }
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.set(e, acc[e]);
+            *(Vec16<T>*)(dup + pix * Cup + cc * EPC) = o;
+        } else {
+            const int64_t j = i - n_up;
+            const int cc = (int)(j % cs);
+            const int64_t pix = j / cs;
+            *(Vec16<T>*)(dskip + pix * Cskip + cc * EPC) = *(const Vec16<T>*)(dcat + pix * Ct + soff + cc * EPC);
+        }
+    }
+}
+
+// arbitrary-stride [B,C,H,W] (fp32 or bf16) -> halo NHWC of T.  One thread per output element (small tensors only).
+template <typename T, typename S>
+__global__ void pack_nchw_kernel(const S* __restrict__ src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, T* __restrict__ dst,
+                                 int pad, int B, int C, int H, int W) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int64_t total = (int64_t)B * Hp * Wp * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int xp = (int)(pix % Wp), yp = (int)((pix / Wp) % Hp), b = (int)(pix / ((int64_t)Wp * Hp));
+        const int y = yp - pad, x = xp - pad;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = to_f(src[b * sb + c * sc + y * sh + x * sw]);
+        dst[i] = from_f<T>(v);
+    }
+}
+
+template <typename TD, typename TS>
+__global__ void cast_nhwc_kernel(const TS* __restrict__ src, int spad, TD* __restrict__ dst, int dpad, int B, int H, int W, int C) {
+    const int Hd = H + 2 * dpad, Wd = W + 2 * dpad, Hs = H + 2 * spad, Ws = W + 2 * spad;
+    const int64_t total = (int64_t)B * Hd * Wd * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int xp = (int)(pix % Wd), yp = (int)((pix / Wd) % Hd), b = (int)(pix / ((int64_t)Wd * Hd));
+        const int y = yp - dpad, x = xp - dpad;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = to_f(src[(((int64_t)b * Hs + y + spad) * Ws + x + spad) * C + c]);
+        dst[i] = from_f<TD>(v);
+    }
+}
+
+inline int stream_grid(int64_t items) {
+    int64_t g = (items + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fva_bn_finalize(const float* part, int32_t nblocks, int64_t count, int32_t C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                    float* save_mean, float* save_rstd, float* scale, float* shift, void* stream) {
+    if (!part || !gamma || !beta || !save_mean || !save_rstd || !scale || !shift || nblocks <= 0 || count <= 0 || C <= 0)
+        return fva_fail(FVA_ERR_ARG, "fva_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblocks, (double)count,
+                       C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, save_mean, save_rstd,
+                       scale, shift);
+    FVA_LAUNCH_CHECK("bn_finalize_kernel");
+    return FVA_OK;
+}
+
+int fva_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                       float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !rm || !rv || !scale || !shift || C <= 0) return fva_fail(FVA_ERR_ARG, "fva_bn_eval_coeffs: bad argument");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, rm, rv, eps,
+                       scale, shift);
+    FVA_LAUNCH_CHECK("bn_eval_coeffs_kernel");
+    return FVA_OK;
+}
+
+static int check_chan(int dtype, int C, const char* who) {
+    if (dtype != FVA_F32 && dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "%s: bad dtype", who);
+    const int epc = dtype == FVA_BF16 ? 8 : 4;
+    if (C <= 0 || C % epc) return fva_fail(FVA_ERR_ARG, "%s: C=%d not a multiple of %d", who, C, epc);
+    return FVA_OK;
+}
+
+int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, int res_pad,
+                      void* z, int z_pad, int B, int H, int W, int C, void* stream) {
+    int rc = check_chan(dtype, C, "fva_bn_silu_apply");
+    if (rc) return rc;
+    if (!y || !scale || !shift || !z) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: null pointer");
+    const HaloIdx h = make_halo(B, H, W, C, z_pad, dtype == FVA_BF16 ? 8 : 4);
+    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(bn_silu_apply_kernel<bf16_t>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                           (const bf16_t*)residual, res_pad, (bf16_t*)z, h);
+    else
+        hipLaunchKernelGGL(bn_silu_apply_kernel<float>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const float*)y, scale, shift,
+                           (const float*)residual, res_pad, (float*)z, h);
+    FVA_LAUNCH_CHECK("bn_silu_apply_kernel");
+    return FVA_OK;
+}
+
+static int bwd_rows_per_block(int64_t M, int C, int epc) {
+    const int rpi = 256 / (C / epc) > 0 ? 256 / (C / epc) : 1;
+    int64_t rows = (M + 2047) / 2048;           // at most 2048 blocks
+    if (rows < (int64_t)rpi * 8) rows = (int64_t)rpi * 8;
+    rows = (rows + rpi - 1) / rpi * rpi;
+    return (int)rows;
+}
+
+int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C) {
+    const int epc = dtype == FVA_BF16 ? 8 : 4;
+    if (C % epc || C / epc > 256 || 256 % (C / epc)) return 0;
+    return cdiv(M, bwd_rows_per_block(M, C, epc));
+}
+
+int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks, int64_t M, int C,
+                           void* stream) {
+    int rc = check_chan(dtype, C, "fva_bn_silu_bwd_reduce");
+    if (rc) return rc;
+    const int epc = dtype == FVA_BF16 ? 8 : 4;
+    const int cpp = C / epc;
+    if (cpp > 256 || 256 % cpp) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: C=%d unsupported", C);
+    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !partial) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: null pointer");
+    const int rows = bwd_rows_per_block(M, C, epc);
+    if (nblocks != cdiv(M, rows)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: nblocks %d != %d", nblocks, cdiv(M, rows));
+    const int smem = 2 * (256 / cpp) * C * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblocks), dim3(256), smem, s, (const bf16_t*)dz, (const bf16_t*)y, scale,
+                           shift, save_mean, save_rstd, partial, M, C, rows);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblocks), dim3(256), smem, s, (const float*)dz, (const float*)y, scale,
+                           shift, save_mean, save_rstd, partial, M, C, rows);
+    FVA_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    return FVA_OK;
+}
+
+int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C, const float* gamma, const float* save_rstd,
+                        float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
+    if (!partial || !gamma || !save_rstd || !dgamma || !dbeta || !coef || nblocks <= 0 || M <= 0 || C <= 0)
+        return fva_fail(FVA_ERR_ARG, "fva_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, (double)M, C,
+                       gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+    FVA_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    return FVA_OK;
+}
+
+int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_rstd, const float* coef, void* dy, int dy_pad, int B, int H, int W, int C, void* stream) {
+    int rc = check_chan(dtype, C, "fva_bn_silu_bwd_apply");
+    if (rc) return rc;
+    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !coef || !dy) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: null pointer");
+    const HaloIdx h = make_halo(B, H, W, C, dy_pad, dtype == FVA_BF16 ? 8 : 4);
+    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
+                           scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const float*)dz, (const float*)y,
+                           scale, shift, save_mean, save_rstd, coef, (float*)dy, h);
+    FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return FVA_OK;
+}
+
+int fva_upsample2_concat_fwd(int dtype, const void* up, int up_pad, const void* skip, int skip_pad, void* out, int B, int h, int w,
+                             int Cup, int Cskip, int up_first, void* stream) {
+    int rc = check_chan(dtype, Cup, "fva_upsample2_concat_fwd");
+    if (!rc) rc = check_chan(dtype, Cskip, "fva_upsample2_concat_fwd");
+    if (rc) return rc;
+    if (!up || !skip || !out) return fva_fail(FVA_ERR_ARG, "fva_upsample2_concat_fwd: null pointer");
+    const HaloIdx hi = make_halo(B, 2 * h, 2 * w, Cup + Cskip, 1, dtype == FVA_BF16 ? 8 : 4);
+    if (hi.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_upsample2_concat_fwd: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(stream_grid(hi.total)), dim3(256), 0, s, (const bf16_t*)up, up_pad,
+                           (const bf16_t*)skip, skip_pad, (bf16_t*)out, hi, h, w, Cup, Cskip, up_first);
+    else
+        hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(stream_grid(hi.total)), dim3(256), 0, s, (const float*)up, up_pad,
+                           (const float*)skip, skip_pad, (float*)out, hi, h, w, Cup, Cskip, up_first);
+    FVA_LAUNCH_CHECK("upcat_fwd_kernel");
+    return FVA_OK;
+}
+
+int fva_upsample2_concat_bwd(int dtype, const void* dcat, void* dup, void* dskip, int B, int h, int w, int Cup, int Cskip,
+                             int up_first, void* stream) {
+    int rc = check_chan(dtype, Cup, "fva_upsample2_concat_bwd");
+    if (!rc) rc = check_chan(dtype, Cskip, "fva_upsample2_concat_bwd");
+    if (rc) return rc;
+    if (!dcat || !dup || !dskip) return fva_fail(FVA_ERR_ARG, "fva_upsample2_concat_bwd: null pointer");
+    const int epc = dtype == FVA_BF16 ? 8 : 4;
+    const int64_t items = (int64_t)B * h * w * (Cup / epc) + (int64_t)B * 4 * h * w * (Cskip / epc);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(upcat_bwd_kernel<bf16_t>, dim3(stream_grid(items)), dim3(256), 0, s, (const bf16_t*)dcat, (bf16_t*)dup,
+                           (bf16_t*)dskip, B, h, w, Cup, Cskip, up_first);
+    else
+        hipLaunchKernelGGL(upcat_bwd_kernel<float>, dim3(stream_grid(items)), dim3(256), 0, s, (const float*)dcat, (float*)dup,
+                           (float*)dskip, B, h, w, Cup, Cskip, up_first);
+    FVA_LAUNCH_CHECK("upcat_bwd_kernel");
+    return FVA_OK;
+}
+
+int fva_pack_nchw(int dtype, const void* src, int src_is_bf16, int64_t sb, int64_t sc, int64_t sh, int64_t sw, void* dst,
+                  int dst_pad, int B, int C, int H, int W, void* stream) {
+    if (!src || !dst || (dtype != FVA_F32 && dtype != FVA_BF16)) return fva_fail(FVA_ERR_ARG, "fva_pack_nchw: bad argument");
+    const int64_t total = (int64_t)B * (H + 2 * dst_pad) * (W + 2 * dst_pad) * C;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(stream_grid(total)), b(256);
+    if (dtype == FVA_BF16 && src_is_bf16)
+        hipLaunchKernelGGL((pack_nchw_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, sb, sc, sh, sw, (bf16_t*)dst, dst_pad, B, C, H, W);
+    else if (dtype == FVA_BF16)
+        hipLaunchKernelGGL((pack_nchw_kernel<bf16_t, float>), g, b, 0, s, (const float*)src, sb, sc, sh, sw, (bf16_t*)dst, dst_pad, B, C, H, W);
+    else if (src_is_bf16)
+        hipLaunchKernelGGL((pack_nchw_kernel<float, bf16_t>), g, b, 0, s, (const bf16_t*)src, sb, sc, sh, sw, (float*)dst, dst_pad, B, C, H, W);
+    else
+        hipLaunchKernelGGL((pack_nchw_kernel<float, float>), g, b, 0, s, (const float*)src, sb, sc, sh, sw, (float*)dst, dst_pad, B, C, H, W);
+    FVA_LAUNCH_CHECK("pack_nchw_kernel");
+    return FVA_OK;
+}
+
+int fva_cast_nhwc(const void* src, int src_dtype, int src_pad, void* dst, int dst_dtype, int dst_pad, int B, int H, int W, int C,
+                  void* stream) {
+    if (!src || !dst) return fva_fail(FVA_ERR_ARG, "fva_cast_nhwc: null pointer");
+    const int64_t total = (int64_t)B * (H + 2 * dst_pad) * (W + 2 * dst_pad) * C;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(stream_grid(total)), b(256);
+    if (dst_dtype == FVA_BF16 && src_dtype == FVA_BF16)
+        hipLaunchKernelGGL((cast_nhwc_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, src_pad, (bf16_t*)dst, dst_pad, B, H, W, C);
+    else if (dst_dtype == FVA_BF16)
+        hipLaunchKernelGGL((cast_nhwc_kernel<bf16_t, float>), g, b, 0, s, (const float*)src, src_pad, (bf16_t*)dst, dst_pad, B, H, W, C);
+    else if (src_dtype == FVA_BF16)
+        hipLaunchKernelGGL((cast_nhwc_kernel<float, bf16_t>), g, b, 0, s, (const bf16_t*)src, src_pad, (float*)dst, dst_pad, B, H, W, C);
+    else
+        hipLaunchKernelGGL((cast_nhwc_kernel<float, float>), g, b, 0, s, (const float*)src, src_pad, (float*)dst, dst_pad, B, H, W, C);
+    FVA_LAUNCH_CHECK("cast_nhwc_kernel");
+    return FVA_OK;
+}
+
+}  // extern "C"

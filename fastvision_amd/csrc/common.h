@@ -1,0 +1,89 @@
+// Shared device/host helpers for libfastvision_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fastvision_amd.h"
+
+typedef __bf16 bf16_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- error reporting -------------------------------------------------------------------------------
+extern thread_local char fva_err_buf[512];
+static inline int fva_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(fva_err_buf, sizeof(fva_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define FVA_LAUNCH_CHECK(name)                                                                     \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) return fva_fail(FVA_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- division by a runtime constant ------------------------------------------------------------------
+struct FastDiv {
+    uint32_t d, mul, sh;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    f.sh = sh;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << sh) - d)) / d + 1);
+    return f;
+}
+// valid for n < 2^31
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.sh; }
+
+// ---- element conversion ------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f(float v);
+template <>
+__device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <>
+struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

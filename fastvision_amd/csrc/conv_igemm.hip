@@ -1,0 +1,580 @@
+// Implicit-GEMM convolution on MFMA for gfx950: forward, data-gradient and the biased detection head.
+//
+//   out[m][n] = sum_t sum_c in[pix(m) + tap_pix[t]][c] * wt[tap_w[t]][n][c]
+//
+// Activations are halo NHWC (channels contiguous, zero border), so a 3x3 tap is a plain pixel offset and
+// needs no bounds check.  One k-tile is a 128-byte slice of channels of one tap (64 bf16 / 32 f32);
+// A (pixels) and B (output channels) tiles are staged by LDS-DMA (global_load_lds, 16 B/lane) into a
+// double-buffered, XOR-swizzled LDS image and consumed with ds_read_b128 + v_mfma_f32_16x16x32_bf16
+// (bf16) or v_mfma_f32_32x32x2_f32 (exact fp32).  Roofline: MFMA-bound (2*M*N*K flop per launch).
+//
+// Replaces nn.Conv2d forward/backward-data as issued by ConvBlock3x3/ConvBlock1x1
+// (reference classfication/models/darknet53.py:5-9, 22-44) and the head conv (detection/head/yolov3head.py:50).
+#include "common.h"
+
+namespace {
+
+enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_HEAD = 2 };
+constexpr int MAX_TAPS = 10;
+
+struct IgemmParams {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stats;
+    const float* bias;
+    int M, N, C;
+    int OW, OHW;
+    FastDiv div_ow, div_ohw;
+    int in_img, in_row;  // pixels
+    int sy, sx, y0, x0;
+    int ktiles, kt_per_tap, halfrow;
+    int tap_pix[MAX_TAPS];
+    int tap_w[MAX_TAPS];
+    int out_dense;  // out pixel index == m
+    int out_img, out_row, osy, osx, ooy, oox, out_pitch;
+    const void* addend;  // optional tensor added in the epilogue (same addressing as out)
+    int nblocks;         // column blocks
+};
+
+template <typename T>
+struct Acc;
+template <>
+struct Acc<bf16_t> {  // per wave 64x64 = 4x4 tiles of 16x16
+    f32x4 a[4][4];
+};
+template <>
+struct Acc<float> {  // per wave 64x64 = 2x2 tiles of 32x32
+    f32x16 a[2][2];
+};
+
+// visit every accumulator element with its (row, col) inside the wave's 64x64 tile
+template <typename F>
+__device__ __forceinline__ void foreach_acc(Acc<bf16_t>& acc, int lane, F&& f) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f(mt * 16 + g * 4 + j, nt * 16 + r, nt, acc.a[mt][nt][j]);
+}
+template <typename F>
+__device__ __forceinline__ void foreach_acc(Acc<float>& acc, int lane, F&& f) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, nt * 32 + r, nt, acc.a[mt][nt][e]);
+}
+
+template <typename T, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;               // 128-byte rows
+    constexpr int WN = BN / 64;               // waves along n
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_ITERS = BM / 32, B_ITERS = BN / 32;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w / WN, wc = w % WN;
+
+    // XCD-aware block order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int mblk = logical / p.nblocks, nblk = logical - mblk * p.nblocks;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+
+    // ---- per-lane source rows for the LDS-DMA (fixed for the whole k loop) -----------------------------
+    const T* a_ptr[A_ITERS];
+    const T* b_ptr[B_ITERS];
+    const int lrow = lane >> 3;
+    const int sw = ((w & 1) << 2) + (lane >> 4);  // ((tile_row >> 1) & 7) of this lane's rows
+    const int chunk = (lane & 7) ^ sw;            // source 16-B chunk that lands at LDS position (lane & 7)
+    const int tapsel = chunk >> 2;                // halfrow: which of the tile's two taps
+    const int sub = p.halfrow ? (chunk & 3) : chunk;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        int m = m0 + (i * 4 + w) * 8 + lrow;
+        m = m < p.M ? m : p.M - 1;
+        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+        const uint32_t oy = fd_div(rem, p.div_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        const int64_t pix = (int64_t)b * p.in_img + (int64_t)(oy * p.sy + p.y0) * p.in_row + (ox * p.sx + p.x0);
+        a_ptr[i] = (const T*)p.in + pix * p.C + sub * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        int n = n0 + (i * 4 + w) * 8 + lrow;
+        n = n < p.N ? n : p.N - 1;
+        b_ptr[i] = (const T*)p.wt + (int64_t)n * p.C + sub * EPC;
+    }
+
+    // per-k-tile element offsets (A: tap pixel offset * C + channel slice; B: tap matrix + channel slice),
+    // tabulated once in LDS so the k loop does no division and no dynamic kernarg indexing
+    int* ktab = (int*)(smem + 2 * STAGE);
+    {
+        const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
+        for (int e = tid; e < nent; e += 256) {
+            int t, kk;
+            if (p.halfrow) { t = e; kk = 0; }
+            else { t = e / p.kt_per_tap; kk = e - t * p.kt_per_tap; }
+            int tp = 0, tw = 0;
+#pragma unroll
+            for (int i = 0; i < MAX_TAPS; ++i)
+                if (i == t) { tp = p.tap_pix[i]; tw = p.tap_w[i]; }
+            ktab[2 * e] = tp * p.C + kk * BK;
+            ktab[2 * e + 1] = tw * p.N * p.C + kk * BK;
+        }
+    }
+    __syncthreads();
+    auto load_tile = [&](int kt, int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + A_BYTES;
+        const int e = p.halfrow ? 2 * kt + tapsel : kt;
+        const int aoff = ktab[2 * e], boff = ktab[2 * e + 1];
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
+    };
+
+    Acc<T> acc;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc.a[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc.a[i][j][e] = 0.f;
+    }
+
+    // ---- main loop: one barrier per k-tile; tile kt+1 is in flight while tile kt is multiplied -----------
+    load_tile(0, 0);
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        __syncthreads();  // own DMA landed (vmcnt(0)) + everyone done with the other stage
+        if (kt + 1 < p.ktiles) load_tile(kt + 1, (kt + 1) & 1);
+        const char* sA = smem + (kt & 1) * STAGE;
+        const char* sB = sA + A_BYTES;
+        if constexpr (IS_BF16) {
+            const int r = lane & 15, g = lane >> 4, sr = (r >> 1) & 7;
+            const char* pa = sA + (wr * 64 + r) * 128;
+            const char* pb = sB + (wc * 64 + r) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((ks * 4 + g) ^ sr) << 4;
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[t] = *(const bf16x8*)(pa + t * 16 * 128 + co);
+                    bfr[t] = *(const bf16x8*)(pb + t * 16 * 128 + co);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc.a[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc.a[mt][nt], 0, 0, 0);
+            }
+        } else {
+            const int r = lane & 31, h = lane >> 5, sr = (r >> 1) & 7;
+            const char* pa = sA + (wr * 64 + r) * 128;
+            const char* pb = sB + (wc * 64 + r) * 128;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = ((2 * q + h) ^ sr) << 4;
+                f32x4 af[2], bfr[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    af[t] = *(const f32x4*)(pa + t * 32 * 128 + co);
+                    bfr[t] = *(const f32x4*)(pb + t * 32 * 128 + co);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc.a[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bfr[nt][j], acc.a[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // LDS is free for the epilogue
+
+    const int wrow0 = wr * 64, wcol0 = wc * 64;
+
+    // ---- BatchNorm partial statistics: per-column sum and sum of squares over this block's valid rows ----
+    if constexpr (EPI == EPI_STATS) {
+        if (p.stats != nullptr) {
+            constexpr int NT = IS_BF16 ? 4 : 2;
+            float s1[NT], s2[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
+            foreach_acc(acc, lane, [&](int row, int, int nt, float v) {
+                const float x = (m0 + wrow0 + row < p.M) ? to_f(from_f<T>(v)) : 0.f;  // stats of the stored values
+                s1[nt] += x;
+                s2[nt] += x * x;
+            });
+            float* red = (float*)smem;  // [2][BM/64][BN]
+            constexpr int WMc = BM / 64;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if constexpr (IS_BF16) {
+                    s1[i] += __shfl_xor(s1[i], 16);
+                    s1[i] += __shfl_xor(s1[i], 32);
+                    s2[i] += __shfl_xor(s2[i], 16);
+                    s2[i] += __shfl_xor(s2[i], 32);
+                    if (lane < 16) {
+                        red[(0 * WMc + wr) * BN + wcol0 + i * 16 + lane] = s1[i];
+                        red[(1 * WMc + wr) * BN + wcol0 + i * 16 + lane] = s2[i];
+                    }
+                } else {
+                    s1[i] += __shfl_xor(s1[i], 32);
+                    s2[i] += __shfl_xor(s2[i], 32);
+                    if (lane < 32) {
+                        red[(0 * WMc + wr) * BN + wcol0 + i * 32 + lane] = s1[i];
+                        red[(1 * WMc + wr) * BN + wcol0 + i * 32 + lane] = s2[i];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, col = tid - which * BN;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
+                if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
+            }
+            __syncthreads();
+        }
+    }
+
+    auto out_pixel = [&](int m) -> int64_t {
+        if (p.out_dense) return m;
+        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+        const uint32_t oy = fd_div(rem, p.div_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        return (int64_t)b * p.out_img + (int64_t)(oy * p.osy + p.ooy) * p.out_row + (ox * p.osx + p.oox);
+    };
+
+    if constexpr (EPI == EPI_HEAD) {
+        // fp32 output with bias, row pitch out_pitch (= N, odd): direct 4-byte stores
+        float* out = (float*)p.out;
+        foreach_acc(acc, lane, [&](int row, int col, int, float v) {
+            const int m = m0 + wrow0 + row, n = n0 + wcol0 + col;
+            if (m < p.M && n < p.N) out[(int64_t)m * p.out_pitch + n] = v + p.bias[n];
+        });
+    } else if constexpr (!IS_BF16) {
+        // fp32: a wave row is 32 lanes x 4 B = one 128-B line already
+        float* out = (float*)p.out;
+        int64_t pix_cache = -1;
+        int m_cache = -1;
+        foreach_acc(acc, lane, [&](int row, int col, int, float v) {
+            const int m = m0 + wrow0 + row, n = n0 + wcol0 + col;
+            if (m < p.M && n < p.N) {
+                if (m != m_cache) {
+                    m_cache = m;
+                    pix_cache = out_pixel(m);
+                }
+                const int64_t oi = pix_cache * p.out_pitch + n;
+                out[oi] = p.addend ? ((const float*)p.addend)[oi] + v : v;
+            }
+        });
+    } else {
+        // bf16: transpose through LDS so that every row leaves as 16-byte pieces
+        constexpr int PITCH = BN * 2 + 16;
+        foreach_acc(acc, lane, [&](int row, int col, int, float v) {
+            *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
+        });
+        __syncthreads();
+        constexpr int CPR = BN / 8;  // 16-B chunks per row
+        constexpr int ITERS = BM * CPR / 256;
+        bf16_t* out = (bf16_t*)p.out;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = it * 256 + tid;
+            const int row = c / CPR, cc = c - row * CPR;
+            const int m = m0 + row, n = n0 + cc * 8;
+            if (m < p.M && n < p.N) {
+                bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
+                const int64_t oi = out_pixel(m) * p.out_pitch + n;
+                if (p.addend) {
+                    const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                }
+                *(bf16x8*)(out + oi) = v;
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int EPI>
+int launch_one(const IgemmParams& p, hipStream_t s) {
+    const int mblocks = cdiv(p.M, BM);
+    IgemmParams q = p;
+    q.nblocks = cdiv(p.N, BN);
+    const int smem = 2 * (BM + BN) * 128 + 4096;  // stages + k-tile offset table
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI>), dim3(mblocks * q.nblocks), dim3(256), smem, s, q);
+    FVA_LAUNCH_CHECK("igemm_kernel");
+    return FVA_OK;
+}
+
+inline bool wide_tile(int N) { return N >= 128; }
+
+template <int EPI>
+int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
+    if (dtype == FVA_BF16) {
+        return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI>(p, s) : launch_one<bf16_t, 256, 64, EPI>(p, s);
+    }
+    return wide_tile(p.N) ? launch_one<float, 128, 128, EPI>(p, s) : launch_one<float, 256, 64, EPI>(p, s);
+}
+
+int check_desc(const fva_conv_desc* d, const char* who) {
+    if (!d) return fva_fail(FVA_ERR_ARG, "%s: null descriptor", who);
+    if (d->dtype != FVA_F32 && d->dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "%s: bad dtype %d", who, d->dtype);
+    if (!((d->ksize == 1 && d->stride == 1) || (d->ksize == 3 && (d->stride == 1 || d->stride == 2))))
+        return fva_fail(FVA_ERR_ARG, "%s: unsupported ksize/stride %d/%d", who, d->ksize, d->stride);
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0)
+        return fva_fail(FVA_ERR_ARG, "%s: non-positive size", who);
+    if (d->stride == 2 && ((d->H | d->W) & 1)) return fva_fail(FVA_ERR_ARG, "%s: stride 2 needs even H, W", who);
+    if (d->in_pad < d->ksize / 2) return fva_fail(FVA_ERR_ARG, "%s: in_pad %d < %d", who, d->in_pad, d->ksize / 2);
+    if ((int64_t)d->B * (d->H + 2) * (d->W + 2) >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "%s: too many pixels", who);
+    return FVA_OK;
+}
+
+// reduction channels must fill 128-byte k-tiles (or be exactly half a bf16 tile)
+int check_red_channels(int dtype, int C, const char* who) {
+    const int bk = dtype == FVA_BF16 ? 64 : 32;
+    if (C % bk == 0) return FVA_OK;
+    if (dtype == FVA_BF16 && C == 32) return FVA_OK;
+    return fva_fail(FVA_ERR_ARG, "%s: reduction channels %d not a multiple of %d", who, C, bk);
+}
+
+inline bool halfrow_mode(int dtype, int C) { return dtype == FVA_BF16 && C == 32; }
+
+void finish_taps(IgemmParams& p, int ntaps, int dtype) {
+    const int bk = dtype == FVA_BF16 ? 64 : 32;
+    p.halfrow = halfrow_mode(dtype, p.C) ? 1 : 0;
+    if (p.halfrow) {
+        if (ntaps & 1) {  // pad with a zero-weight tap (packed weights carry the zero tap at index k*k)
+            p.tap_pix[ntaps] = p.tap_pix[0];
+            p.tap_w[ntaps] = p.tap_w[ntaps];  // set by caller
+        }
+        p.ktiles = (ntaps + 1) / 2;
+        p.kt_per_tap = 1;
+    } else {
+        p.kt_per_tap = p.C / bk;
+        p.ktiles = ntaps * p.kt_per_tap;
+    }
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void* dgr, int Cout, int Cin, int kk,
+                                    int taps_f, int taps_d, int bf16) {
+    // one thread per (tap, co, ci) of the padded space max(taps_f, taps_d) x Cout x Cin
+    const int64_t total = (int64_t)(taps_f > taps_d ? taps_f : taps_d) * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const int co = (int)((i / Cin) % Cout);
+        const int t = (int)(i / ((int64_t)Cin * Cout));
+        const float v = t < kk ? w[((int64_t)co * Cin + ci) * kk + t] : 0.f;
+        if (fwd && t < taps_f) {
+            const int64_t o = ((int64_t)t * Cout + co) * Cin + ci;
+            if (bf16) ((bf16_t*)fwd)[o] = (bf16_t)v; else ((float*)fwd)[o] = v;
+        }
+        if (dgr && t < taps_d) {
+            const int64_t o = ((int64_t)t * Cin + ci) * Cout + co;
+            if (bf16) ((bf16_t*)dgr)[o] = (bf16_t)v; else ((float*)dgr)[o] = v;
+        }
+    }
+}
+
+int packed_taps(const fva_conv_desc* d, int for_dgrad) {
+    const int kk = d->ksize * d->ksize;
+    const int C = for_dgrad ? d->Cout : d->Cin;
+    return (halfrow_mode(d->dtype, C) && (kk & 1)) ? kk + 1 : kk;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad) {
+    if (!d) return 0;
+    return (int64_t)packed_taps(d, for_dgrad) * d->Cout * d->Cin;
+}
+
+int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad, void* stream) {
+    int rc = check_desc(d, "fva_conv_pack_weights");
+    if (rc) return rc;
+    if (!w) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights: null weights");
+    const int tf = packed_taps(d, 0), td = packed_taps(d, 1);
+    const int64_t total = (int64_t)(tf > td ? tf : td) * d->Cout * d->Cin;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_dgrad, d->Cout,
+                       d->Cin, d->ksize * d->ksize, tf, td, d->dtype == FVA_BF16 ? 1 : 0);
+    FVA_LAUNCH_CHECK("pack_weights_kernel");
+    return FVA_OK;
+}
+
+int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
+    if (!d) return 0;
+    const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
+    const int64_t M = (int64_t)d->B * OH * OW;
+    return cdiv(M, wide_tile(d->Cout) ? 128 : 256);
+}
+
+static int setup_fwd(const fva_conv_desc* d, IgemmParams& p, const char* who) {
+    int rc = check_desc(d, who);
+    if (rc) return rc;
+    rc = check_red_channels(d->dtype, d->Cin, who);
+    if (rc) return rc;
+    const int k = d->ksize, s = d->stride;
+    const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
+    p = IgemmParams();
+    p.M = d->B * OH * OW;
+    p.N = d->Cout;
+    p.C = d->Cin;
+    p.OW = OW;
+    p.OHW = OH * OW;
+    p.div_ow = make_fastdiv(OW);
+    p.div_ohw = make_fastdiv(OH * OW);
+    p.in_row = d->W + 2 * d->in_pad;
+    p.in_img = (d->H + 2 * d->in_pad) * p.in_row;
+    p.sy = p.sx = s;
+    p.y0 = p.x0 = d->in_pad - k / 2;
+    int nt = 0;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            p.tap_pix[nt] = kh * p.in_row + kw;
+            p.tap_w[nt] = kh * k + kw;
+            ++nt;
+        }
+    p.tap_w[nt] = k * k;  // zero tap (present in packed weights when needed)
+    finish_taps(p, nt, d->dtype);
+    p.out_dense = 1;
+    p.out_pitch = d->Cout;
+    return FVA_OK;
+}
+
+int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_conv_fwd");
+    if (rc) return rc;
+    if (!x || !w_fwd || !y) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd: null pointer");
+    if (d->Cout % 8) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd: Cout %d not a multiple of 8", d->Cout);
+    p.in = x;
+    p.wt = w_fwd;
+    p.out = y;
+    p.stats = stats_partial;
+    return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
+}
+
+int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_head_fwd");
+    if (rc) return rc;
+    if (d->ksize != 1) return fva_fail(FVA_ERR_ARG, "fva_head_fwd: ksize must be 1");
+    if (!x || !w_fwd || !bias || !out) return fva_fail(FVA_ERR_ARG, "fva_head_fwd: null pointer");
+    p.in = x;
+    p.wt = w_fwd;
+    p.out = out;
+    p.bias = bias;
+    return launch_igemm<EPI_HEAD>(d->dtype, p, (hipStream_t)stream);
+}
+
+int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream) {
+    int rc = check_desc(d, "fva_conv_dgrad");
+    if (rc) return rc;
+    rc = check_red_channels(d->dtype, d->Cout, "fva_conv_dgrad");
+    if (rc) return rc;
+    if (!dy || !w_dgrad || !dx) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: null pointer");
+    if (d->Cin % 8) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: Cin %d not a multiple of 8", d->Cin);
+    const int k = d->ksize, s = d->stride, pd = k / 2;
+    if (d->dy_pad < pd) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: dy_pad %d < %d", d->dy_pad, pd);
+    const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
+    IgemmParams p = IgemmParams();
+    p.in = dy;
+    p.wt = w_dgrad;
+    p.out = dx;
+    p.N = d->Cin;
+    p.C = d->Cout;
+    p.in_row = OW + 2 * d->dy_pad;
+    p.in_img = (OH + 2 * d->dy_pad) * p.in_row;
+    p.sy = p.sx = 1;
+    p.addend = addend;
+    p.out_pitch = d->Cin;
+    if (s == 1) {
+        p.M = d->B * d->H * d->W;
+        p.OW = d->W;
+        p.OHW = d->H * d->W;
+        p.div_ow = make_fastdiv(p.OW);
+        p.div_ohw = make_fastdiv(p.OHW);
+        p.y0 = p.x0 = d->dy_pad - pd;
+        int nt = 0;
+        for (int kh = 0; kh < k; ++kh)
+            for (int kw = 0; kw < k; ++kw) {
+                p.tap_pix[nt] = (2 * pd - kh) * p.in_row + (2 * pd - kw);
+                p.tap_w[nt] = kh * k + kw;
+                ++nt;
+            }
+        p.tap_w[nt] = k * k;
+        finish_taps(p, nt, d->dtype);
+        p.out_dense = 1;
+        return launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+    }
+    // stride 2, 3x3: four output-parity classes, each with its own tap subset (no wasted MACs)
+    const int JH = d->H / 2, JW = d->W / 2;
+    p.M = d->B * JH * JW;
+    p.OW = JW;
+    p.OHW = JH * JW;
+    p.div_ow = make_fastdiv(p.OW);
+    p.div_ohw = make_fastdiv(p.OHW);
+    p.y0 = p.x0 = 0;
+    p.out_dense = 0;
+    p.out_img = d->H * d->W;
+    p.out_row = d->W;
+    p.osy = p.osx = 2;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            int khs[2], yo[2], nky, kws[2], xo[2], nkx;
+            if (py == 0) { nky = 1; khs[0] = 1; yo[0] = d->dy_pad; }
+            else { nky = 2; khs[0] = 0; yo[0] = d->dy_pad + 1; khs[1] = 2; yo[1] = d->dy_pad; }
+            if (px == 0) { nkx = 1; kws[0] = 1; xo[0] = d->dy_pad; }
+            else { nkx = 2; kws[0] = 0; xo[0] = d->dy_pad + 1; kws[1] = 2; xo[1] = d->dy_pad; }
+            int nt = 0;
+            for (int a = 0; a < nky; ++a)
+                for (int b = 0; b < nkx; ++b) {
+                    p.tap_pix[nt] = yo[a] * p.in_row + xo[b];
+                    p.tap_w[nt] = khs[a] * 3 + kws[b];
+                    ++nt;
+                }
+            p.tap_w[nt] = 9;
+            finish_taps(p, nt, d->dtype);
+            p.ooy = py;
+            p.oox = px;
+            rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return FVA_OK;
+}
+
+}  // extern "C"

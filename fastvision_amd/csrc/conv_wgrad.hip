@@ -1,0 +1,293 @@
+// Weight gradient of the convolution on MFMA for gfx950 (split-K over pixels, deterministic reduce).
+//
+//   dW[t][n][c] = sum_m dY[m][n] * X[pix(m) + tap_pix[t]][c]          m = (b, oy, ox)
+//
+// Both operands are pixel-major NHWC (channels contiguous), i.e. the contraction index m is the SLOW axis of
+// both.  Tiles of 64 pixels x 256 bytes of channels are staged by LDS-DMA; the bf16 MFMA fragments (8
+// consecutive k per lane) are read with ds_read_b64_tr_b16, the gfx950 transposing LDS read, from an
+// XOR-swizzled image (conflict-free for the 16x16x32 operand).  fp32 uses v_mfma_f32_32x32x2_f32 whose
+// operands are one float per lane, read straight out of the pixel-major image.
+// Each block owns one [n-tile x c-tile] of one tap over one pixel range and writes an fp32 partial tile to
+// the workspace slab [ksplit][tap][N][C]; a second kernel sums the partials in fixed order into the OIHW
+// fp32 gradient.  Roofline: MFMA-bound (2*M*N*C*taps flop).
+//
+// Replaces the backward-weight of nn.Conv2d (reference classfication/models/darknet53.py:5-9 via autograd).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    const void* x;
+    const void* dy;
+    float* slab;
+    int M, N, C;
+    int OW, OHW;
+    FastDiv div_ow, div_ohw;
+    int x_img, x_row, sy, sx, x_y0, x_x0;
+    int dy_img, dy_row, dy_pad, dy_pitch;
+    int64_t dy_zero_pix;
+    int ntaps;
+    int tap_pix[9];
+    int ntn, ntc, ksplit, mchunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int TILE = 16 * EPC;  // channels per tile side: 128 bf16 / 64 f32 (256-byte rows)
+    constexpr int BKP = 64;         // pixels per k-step
+    constexpr int OP_BYTES = BKP * 256, STAGE = 2 * OP_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int per_ks = p.ntaps * p.ntn * p.ntc;
+    const int ks = logical / per_ks;
+    logical -= ks * per_ks;
+    const int tap = logical / (p.ntn * p.ntc);
+    logical -= tap * (p.ntn * p.ntc);
+    const int tn = logical / p.ntc, tc = logical - tn * p.ntc;
+    const int n0 = tn * TILE, c0 = tc * TILE;
+    const int mbeg = ks * p.mchunk;
+    const int mend = (mbeg + p.mchunk < p.M) ? mbeg + p.mchunk : p.M;
+    const int steps = p.mchunk / BKP;
+
+    // tap pixel offset without dynamic kernarg indexing
+    int tpix = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (i == tap) tpix = p.tap_pix[i];
+
+    // ---- LDS-DMA source mapping: one instruction = 4 pixel rows x 256 B; lane -> (row, 16-B chunk) ---------
+    const int lrow = lane >> 4;
+    const int f = IS_BF16 ? ((lrow << 2) | w) : 0;  // swizzle of this lane's rows: ((R&3)<<2)|((R>>2)&3)
+    const int chunk = (lane & 15) ^ f;
+    const bool a_ok = n0 + chunk * EPC < p.N;  // columns beyond N / C feed only unused outputs: point them
+    const bool b_ok = c0 + chunk * EPC < p.C;  // at column 0 to stay inside the buffers
+    const int a_col = a_ok ? n0 + chunk * EPC : 0;
+    const int b_col = b_ok ? c0 + chunk * EPC : 0;
+
+    auto load_step = [&](int step, int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + OP_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = (i * 4 + w) * 4 + lrow;
+            int m = mbeg + step * BKP + R;
+            const bool live = m < mend;
+            m = m < p.M ? m : p.M - 1;
+            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+            const uint32_t oy = fd_div(rem, p.div_ow);
+            const uint32_t ox = rem - oy * (uint32_t)p.OW;
+            const int64_t dpix = live ? (int64_t)b * p.dy_img + (int64_t)(oy + p.dy_pad) * p.dy_row + (ox + p.dy_pad)
+                                      : p.dy_zero_pix;
+            const int64_t xpix = (int64_t)b * p.x_img + (int64_t)(oy * p.sy + p.x_y0) * p.x_row + (ox * p.sx + p.x_x0) + tpix;
+            const T* ga = (const T*)p.dy + dpix * p.dy_pitch + a_col;
+            const T* gb = (const T*)p.x + xpix * p.C + b_col;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ga), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gb), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc16[4][4];
+    f32x16 acc32;
+    if constexpr (IS_BF16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[e] = 0.f;
+    }
+
+    load_step(0, 0);
+    for (int st = 0; st < steps; ++st) {
+        __syncthreads();
+        if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
+        const char* sA = smem + (st & 1) * STAGE;
+        const char* sB = sA + OP_BYTES;
+        if constexpr (IS_BF16) {
+            // transposed read: lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a
+            // 4-row x 16-column block and receives column (lane&15) of the 4 rows
+            const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = kk * 32 + 8 * g + 4 * hh + q;
+                    const int fr = (q << 2) | ((2 * g + hh) & 3);
+                    const int rbase = row * 256 + 8 * (pp & 1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int cha = wr * 8 + t * 2 + (pp >> 1);
+                        const int chb = wc * 8 + t * 2 + (pp >> 1);
+                        const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sA + rbase + ((cha ^ fr) << 4)));
+                        const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sB + rbase + ((chb ^ fr) << 4)));
+                        const bf16x4 ba = __builtin_bit_cast(bf16x4, va), bb = __builtin_bit_cast(bf16x4, vb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            af[t][hh * 4 + e] = ba[e];
+                            bfr[t][hh * 4 + e] = bb[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc16[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[ct], acc16[nt][ct], 0, 0, 0);
+            }
+        } else {
+            const int r = lane & 31, h = lane >> 5;
+            const float* fa = (const float*)sA + wr * 32 + r;
+            const float* fb = (const float*)sB + wc * 32 + r;
+#pragma unroll 8
+            for (int k2 = 0; k2 < 32; ++k2) {
+                const float a = fa[(2 * k2 + h) * 64];
+                const float b = fb[(2 * k2 + h) * 64];
+                acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial tile -> slab[ks][tap][N][C] ------------------------------------------------------------
+    float* out = p.slab + ((int64_t)ks * p.ntaps + tap) * p.N * p.C;
+    if constexpr (IS_BF16) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wr * 64 + nt * 16 + g * 4 + j, c = c0 + wc * 64 + ct * 16 + r;
+                    if (n < p.N && c < p.C) out[(int64_t)n * p.C + c] = acc16[nt][ct][j];
+                }
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = n0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, c = c0 + wc * 32 + r;
+            if (n < p.N && c < p.C) out[(int64_t)n * p.C + c] = acc32[e];
+        }
+    }
+}
+
+// dw[n][c][t] (+)= sum_ks slab[ks][t][n][c]; one thread per (n, c) writes its k*k taps contiguously
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N, int C, int ntaps,
+                                    int ksplit, int accumulate) {
+    const int64_t nc = (int64_t)N * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nc; i += (int64_t)gridDim.x * blockDim.x) {
+        for (int t = 0; t < ntaps; ++t) {
+            float s = 0.f;
+            for (int k = 0; k < ksplit; ++k) s += slab[((int64_t)k * ntaps + t) * nc + i];
+            float* o = dw + i * ntaps + t;
+            *o = accumulate ? *o + s : s;
+        }
+    }
+}
+
+struct WgradPlan {
+    int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW;
+};
+
+int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
+    pl.tile = d->dtype == FVA_BF16 ? 128 : 64;
+    pl.OH = (d->H - 1) / d->stride + 1;
+    pl.OW = (d->W - 1) / d->stride + 1;
+    pl.M = d->B * pl.OH * pl.OW;
+    pl.ntn = cdiv(d->Cout, pl.tile);
+    pl.ntc = cdiv(d->Cin, pl.tile);
+    pl.ntaps = d->ksize * d->ksize;
+    const int tiles = pl.ntn * pl.ntc * pl.ntaps;
+    int ks = cdiv(1024, tiles);
+    const int max_by_m = cdiv(pl.M, 256);
+    if (ks > max_by_m) ks = max_by_m;
+    const int64_t per = (int64_t)pl.ntaps * d->Cout * d->Cin * 4;
+    const int64_t max_by_ws = (512ll << 20) / per;
+    if (ks > max_by_ws) ks = (int)max_by_ws;
+    if (ks < 1) ks = 1;
+    pl.mchunk = cdiv(cdiv(pl.M, ks), 64) * 64;
+    pl.ksplit = cdiv(pl.M, pl.mchunk);
+    return FVA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d) {
+    if (!d) return 0;
+    WgradPlan pl;
+    plan_wgrad(d, pl);
+    return (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
+}
+
+int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+    if (!d || !x || !dy || !dw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: null pointer");
+    if (d->dtype != FVA_F32 && d->dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: bad dtype");
+    if (!((d->ksize == 1 && d->stride == 1) || (d->ksize == 3 && (d->stride == 1 || d->stride == 2))))
+        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: unsupported ksize/stride");
+    const int epc = d->dtype == FVA_BF16 ? 8 : 4;
+    if (d->Cin % epc || d->Cout % epc) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: channels must be multiples of %d", epc);
+    if (d->in_pad < d->ksize / 2) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: in_pad too small");
+    if (d->dy_pad < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: dy buffer needs a zero border (dy_pad >= 1)");
+    WgradPlan pl;
+    plan_wgrad(d, pl);
+    const int64_t need = (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
+    if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_conv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
+    WgradParams p = WgradParams();
+    p.x = x;
+    p.dy = dy;
+    p.slab = (float*)workspace;
+    p.M = pl.M;
+    p.N = d->Cout;
+    p.C = d->Cin;
+    p.OW = pl.OW;
+    p.OHW = pl.OH * pl.OW;
+    p.div_ow = make_fastdiv(p.OW);
+    p.div_ohw = make_fastdiv(p.OHW);
+    p.x_row = d->W + 2 * d->in_pad;
+    p.x_img = (d->H + 2 * d->in_pad) * p.x_row;
+    p.sy = p.sx = d->stride;
+    p.x_y0 = p.x_x0 = d->in_pad - d->ksize / 2;
+    p.dy_row = pl.OW + 2 * d->dy_pad;
+    p.dy_img = (pl.OH + 2 * d->dy_pad) * p.dy_row;
+    p.dy_pad = d->dy_pad;
+    p.dy_pitch = d->Cout;
+    p.dy_zero_pix = 0;  // top-left border pixel of image 0 is always zero
+    p.ntaps = pl.ntaps;
+    for (int kh = 0; kh < d->ksize; ++kh)
+        for (int kw = 0; kw < d->ksize; ++kw) p.tap_pix[kh * d->ksize + kw] = kh * p.x_row + kw;
+    p.ntn = pl.ntn;
+    p.ntc = pl.ntc;
+    p.ksplit = pl.ksplit;
+    p.mchunk = pl.mchunk;
+    const int grid = pl.ksplit * pl.ntaps * pl.ntn * pl.ntc;
+    const int smem = 2 * 2 * 64 * 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == FVA_BF16)
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), smem, s, p);
+    FVA_LAUNCH_CHECK("wgrad_kernel");
+    const int64_t nc = (int64_t)d->Cout * d->Cin;
+    const int rgrid = (int)((nc + 255) / 256 < 2048 ? (nc + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, d->Cout, d->Cin,
+                       pl.ntaps, pl.ksplit, accumulate);
+    FVA_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return FVA_OK;
+}
+
+}  // extern "C"

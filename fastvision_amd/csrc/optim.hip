@@ -1,0 +1,53 @@
+// Multi-tensor Adam for gfx950 with torch.optim.Adam's exact update order (single-tensor path of
+// torch/optim/adam.py): L2 decay folded into the gradient, lerp for exp_avg, sqrt(v)/sqrt(bc2) + eps.
+// HBM-bound: 16 B read + 12 B written per parameter; one launch for all tensors (blockIdx.y = tensor).
+//
+// Replaces torch.optim.Adam(..., betas=(0.937, 0.999), weight_decay=5e-4).step() as built by the reference
+// (demos/yolov3_u/train.py:66-70).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(const void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, int n,
+                                                   float step_size, float bc2_sqrt, float beta1, float beta2, float eps, float wd,
+                                                   float gscale) {
+    const int t = blockIdx.y;
+    const int64_t size = sizes[t];
+    float* p = (float*)ptrs[t];
+    const float* g = (const float*)ptrs[n + t];
+    float* m = (float*)ptrs[2 * n + t];
+    float* v = (float*)ptrs[3 * n + t];
+    if (g == nullptr) return;  // parameter without a gradient this step (torch skips it too)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < size; i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[i] * gscale;
+        const float pv = p[i];
+        if (wd != 0.f) gr = gr + wd * pv;
+        float mi = m[i], vi = v[i];
+        mi = mi + (gr - mi) * (1.f - beta1);
+        vi = vi * beta2 + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pv - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+}  // namespace
+
+extern "C" int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    if (!ptrs || !sizes || n < 1 || step < 1) return fva_fail(FVA_ERR_ARG, "fva_adam_step: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int64_t gx = (max_size + 1023) / 1024;
+    if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, ptrs, sizes, n, step_size, bc2_sqrt, beta1,
+                       beta2, eps, weight_decay, grad_scale);
+    FVA_LAUNCH_CHECK("adam_kernel");
+    return FVA_OK;
+}

@@ -1,0 +1,204 @@
+// Stem convolution (3x3, stride 1, pad 1, Cin <= 4, Cout == 32) read straight from the caller's fp32 NCHW
+// images: 27-deep dot products are too shallow for MFMA, so this is a direct VALU kernel, one output pixel
+// (all 32 channels) per lane.  HBM-bound: reads 12 B and writes 64 B (bf16) per pixel.
+//
+// Replaces `conv0` of Darknet-53 (reference classfication/models/darknet53.py:73) forward and weight gradient
+// (the input image needs no gradient).
+#include "common.h"
+
+namespace {
+
+constexpr int CO = 32;      // output channels handled
+constexpr int MAXJ = 36;    // Cin*9 <= 36
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                       T* __restrict__ y, float* __restrict__ stats, int B, int Cin, int H,
+                                                       int W, int64_t M) {
+    __shared__ float sw[MAXJ * CO];
+    __shared__ float tile[256 * 33];
+    const int tid = threadIdx.x;
+    const int J = Cin * 9;
+    for (int i = tid; i < J * CO; i += 256) {
+        const int co = i % CO, j = i / CO;  // sw[j][co] = w[co][ci][kh][kw], j = ci*9 + kh*3 + kw
+        sw[j * CO + co] = w[co * J + j];
+    }
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = m < M;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    if (live) {
+        const int x = (int)(m % W), yy = (int)((m / W) % H), b = (int)(m / ((int64_t)W * H));
+#pragma unroll 1
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* plane = img + ((int64_t)b * Cin + ci) * H * W;
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iy = yy + kh - 1, ix = x + kw - 1;
+                    const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(int64_t)iy * W + ix] : 0.f;
+                    const float4* wr = (const float4*)&sw[(ci * 9 + kh * 3 + kw) * CO];
+#pragma unroll
+                    for (int q = 0; q < CO / 4; ++q) {
+                        const float4 ww = wr[q];
+                        acc[4 * q + 0] += v * ww.x;
+                        acc[4 * q + 1] += v * ww.y;
+                        acc[4 * q + 2] += v * ww.z;
+                        acc[4 * q + 3] += v * ww.w;
+                    }
+                }
+        }
+        constexpr int EPC = Vec16<T>::N;
+#pragma unroll
+        for (int q = 0; q < CO / EPC; ++q) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.set(e, acc[q * EPC + e]);
+            *(Vec16<T>*)(y + m * CO + q * EPC) = o;
+        }
+    }
+    if (stats == nullptr) return;
+    // BatchNorm partials of the STORED values: [blk][2][32]
+#pragma unroll
+    for (int c = 0; c < CO; ++c) tile[tid * 33 + c] = live ? to_f(from_f<T>(acc[c])) : 0.f;
+    __syncthreads();
+    const int c = tid & 31, grp = tid >> 5;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = grp; p < 256; p += 8) {
+        const float v = tile[p * 33 + c];
+        s1 += v;
+        s2 += v * v;
+    }
+    __syncthreads();
+    tile[grp * 64 + c] = s1;
+    tile[grp * 64 + 32 + c] = s2;
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += tile[g * 64 + tid];
+        stats[((int64_t)blockIdx.x * 2 + (tid >> 5)) * CO + (tid & 31)] = s;
+    }
+}
+
+// dW partial per block over a strided set of 128-pixel tiles: slab[blk][co][j].  Lanes 0-127 stage the dY rows,
+// lanes 128-255 the 3x3 input patches; then lane (co, jg) accumulates outputs j = jg, jg+8, ...
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy,
+                                                         float* __restrict__ slab, int B, int Cin, int H, int W, int64_t M,
+                                                         int ntiles) {
+    __shared__ float sdy[128 * 33];
+    __shared__ float spt[128 * 37];
+    const int tid = threadIdx.x;
+    const int J = Cin * 9;
+    const int co = tid & 31, jg = tid >> 5;
+    const int px = tid & 127, role = tid >> 7;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // j = jg + 8*i, i < 5 (J <= 36)
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t m = (int64_t)t * 128 + px;
+        const bool live = m < M;
+        constexpr int EPC = Vec16<T>::N;
+        if (role == 0) {
+#pragma unroll
+            for (int q = 0; q < CO / EPC; ++q) {
+                Vec16<T> v;
+                if (live) v = *(const Vec16<T>*)(dy + m * CO + q * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) sdy[px * 33 + q * EPC + e] = live ? v.get(e) : 0.f;
+            }
+        } else {
+            const int x = (int)(m % W), yy = (int)((m / W) % H), b = (int)(m / ((int64_t)W * H));
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float* plane = img + ((int64_t)b * Cin + ci) * H * W;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int iy = yy + kh - 1, ix = x + kw - 1;
+                        spt[px * 37 + ci * 9 + kh * 3 + kw] =
+                            (live && iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(int64_t)iy * W + ix] : 0.f;
+                    }
+            }
+        }
+        __syncthreads();
+        for (int p = 0; p < 128; ++p) {
+            const float g = sdy[p * 33 + co];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int j = jg + 8 * i;
+                if (j < J) acc[i] += g * spt[p * 37 + j];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int j = jg + 8 * i;
+        if (j < J) slab[((int64_t)blockIdx.x * CO + co) * J + j] = acc[i];
+    }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int n, int nblocks, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+constexpr int WGRAD_BLOCKS = 1024;
+
+}  // namespace
+
+extern "C" {
+
+int32_t fva_stem_stat_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, 256); }
+
+int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* stats, int B, int Cin, int H, int W, int Cout,
+                 void* stream) {
+    if (!img || !w || !y) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: null pointer");
+    if (Cout != CO || Cin < 1 || Cin > 4) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: needs Cout==32, Cin<=4 (got %d, %d)", Cout, Cin);
+    const int64_t M = (int64_t)B * H * W;
+    const int grid = cdiv(M, 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, w, (bf16_t*)y, stats, B, Cin, H, W, M);
+    else if (dtype == FVA_F32)
+        hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, img, w, (float*)y, stats, B, Cin, H, W, M);
+    else
+        return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: bad dtype");
+    FVA_LAUNCH_CHECK("stem_fwd_kernel");
+    return FVA_OK;
+}
+
+int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout) {
+    (void)B; (void)H; (void)W;
+    return (int64_t)WGRAD_BLOCKS * Cout * Cin * 9 * 4;
+}
+
+int fva_stem_wgrad(int dtype, const float* img, const void* dy, float* dw, int accumulate, void* workspace, int64_t workspace_bytes,
+                   int B, int Cin, int H, int W, int Cout, void* stream) {
+    if (!img || !dy || !dw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: null pointer");
+    if (Cout != CO || Cin < 1 || Cin > 4) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: needs Cout==32, Cin<=4");
+    if (workspace_bytes < fva_stem_wgrad_workspace(B, Cin, H, W, Cout)) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_wgrad: workspace too small");
+    const int64_t M = (int64_t)B * H * W;
+    const int ntiles = cdiv(M, 128);
+    const int grid = ntiles < WGRAD_BLOCKS ? ntiles : WGRAD_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, (const bf16_t*)dy, (float*)workspace, B, Cin, H, W, M, ntiles);
+    else if (dtype == FVA_F32)
+        hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), 0, s, img, (const float*)dy, (float*)workspace, B, Cin, H, W, M, ntiles);
+    else
+        return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: bad dtype");
+    FVA_LAUNCH_CHECK("stem_wgrad_kernel");
+    const int n = Cout * Cin * 9;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, grid, accumulate);
+    FVA_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
+    return FVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+from .BOX import *   # noqa: F401,F403
+from .GRID import *  # noqa: F401,F403
+from .IOU import *   # noqa: F401,F403

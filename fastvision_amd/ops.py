@@ -1,0 +1,445 @@
+"""Host-side glue between torch tensors / autograd and the C ABI (include/fastvision_amd.h).
+
+PyTorch is plumbing here: device memory, streams and the autograd tape.  All arithmetic on the hot path runs
+in the HIP kernels of libfastvision_amd.so; there is no PyTorch or CPU fallback (CPU tensors raise).
+
+Activation convention: a feature map is an ordinary ``torch.Tensor`` of logical shape [B,C,H,W] that is a
+strided *view* of a halo NHWC buffer [B,H+2,W+2,C] (zero border).  Modules hand these views to each other
+zero-copy; foreign tensors (any strides, fp32/bf16) are packed on entry.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvDesc
+
+_state = threading.local()
+_default_dtype = torch.bfloat16
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (default: bf16 storage, fp32 accumulate) or torch.float32 (exact fp32 MFMA path)."""
+    global _default_dtype
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError('compute dtype must be torch.bfloat16 or torch.float32')
+    _default_dtype = dtype
+
+
+def get_compute_dtype():
+    return getattr(_state, 'dtype', None) or _default_dtype
+
+
+class compute_dtype:
+    """Context manager: ``with compute_dtype(torch.float32): ...``"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = getattr(_state, 'dtype', None)
+        _state.dtype = self.dtype
+
+    def __exit__(self, *a):
+        _state.dtype = self.prev
+
+
+def _code(dtype):
+    return BF16 if dtype == torch.bfloat16 else F32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f'fastvision_amd.{who}: tensors must live on the GPU -- this package has no CPU path '
+                           '(the CPU oracle lives under oracle/ and is test infrastructure only)')
+
+
+# ------------------------------------------------------------------------------------------------ layouts
+def halo_alloc(B, Cc, H, W, dtype, device, pad=1):
+    """Uninitialised halo buffer [B,H+2p,W+2p,C] and its logical [B,C,H,W] view (kernels write the border)."""
+    buf = torch.empty((B, H + 2 * pad, W + 2 * pad, Cc), dtype=dtype, device=device)
+    return buf, buf[:, pad:pad + H, pad:pad + W, :].permute(0, 3, 1, 2)
+
+
+def halo_info(x, dtype):
+    """If x [B,C,H,W] is a view of a halo buffer of ``dtype`` return (base_ptr, pad); else None."""
+    if x.dim() != 4 or x.dtype != dtype:
+        return None
+    B, Cc, H, W = x.shape
+    item = x.element_size()
+    for pad in (1, 0):
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+        if tuple(x.stride()) == (Hp * Wp * Cc, 1, Wp * Cc, Cc):
+            lead = pad * (Wp + 1) * Cc
+            tail = (B * Hp * Wp * Cc) - lead
+            st = x.untyped_storage()
+            off = x.storage_offset()
+            if off >= lead and (off + tail) * item <= st.nbytes():
+                return x.data_ptr() - lead * item, pad
+    return None
+
+
+def to_halo(x, dtype, min_pad):
+    """Return (keepalive, base_ptr, pad) for x in halo layout of ``dtype`` with pad >= min_pad (packing if needed)."""
+    info = halo_info(x, dtype)
+    if info is not None and info[1] >= min_pad:
+        return x, info[0], info[1]
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    B, Cc, H, W = x.shape
+    buf, _ = halo_alloc(B, Cc, H, W, dtype, x.device, 1)
+    sb, sc, sh, sw = x.stride()
+    _lib.call('fva_pack_nchw', _code(dtype), _p(x), 1 if x.dtype == torch.bfloat16 else 0, sb, sc, sh, sw, _p(buf), 1,
+              B, Cc, H, W, _stream())
+    return buf, buf.data_ptr(), 1
+
+
+def to_dense(g, dtype):
+    """Gradient [B,C,H,W] -> (keepalive, ptr) of a dense NHWC buffer of ``dtype`` (zero-copy when it already is one)."""
+    info = halo_info(g, dtype)
+    if info is not None and info[1] == 0:
+        return g, info[0]
+    B, Cc, H, W = g.shape
+    if g.dtype not in (torch.float32, torch.bfloat16):
+        g = g.float()
+    buf = torch.empty((B, H, W, Cc), dtype=dtype, device=g.device)
+    sb, sc, sh, sw = g.stride()
+    _lib.call('fva_pack_nchw', _code(dtype), _p(g), 1 if g.dtype == torch.bfloat16 else 0, sb, sc, sh, sw, _p(buf), 0,
+              B, Cc, H, W, _stream())
+    return buf, buf.data_ptr()
+
+
+def dense_view(buf):
+    """Dense NHWC buffer [B,H,W,C] -> logical [B,C,H,W] view."""
+    return buf.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ conv + BN + SiLU
+class _BNState:
+    """Tensors of one nn.BatchNorm2d that the kernels update in place."""
+
+    def __init__(self, bn):
+        self.rm, self.rv, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        self.momentum = 0.1 if bn.momentum is None else bn.momentum
+        self.eps = bn.eps
+
+
+def packed_weights(weight, desc, dtype, cache=True):
+    """(w_fwd, w_dgrad) in the MFMA operand layouts.  The pair is cached ON the parameter object and re-packed
+    only when its autograd version counter (bumped by every in-place update, incl. FusedAdam) or data moved."""
+    key = (weight._version, weight.data_ptr(), desc.dtype)
+    hit = getattr(weight, '_fva_packed', None) if cache else None
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    lib = _lib.load()
+    wf = torch.empty(lib.fva_conv_packed_elems(C.byref(desc), 0), dtype=dtype, device=weight.device)
+    wd = torch.empty(lib.fva_conv_packed_elems(C.byref(desc), 1), dtype=dtype, device=weight.device)
+    _lib.call('fva_conv_pack_weights', C.byref(desc), _p(weight), _p(wf), _p(wd), _stream())
+    if cache:
+        weight._fva_packed = (key, wf, wd)
+    return wf, wd
+
+
+class _Saved:
+    pass
+
+
+def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
+    """SiLU(BN(conv(x))) [+ residual].  x: logical [B,Cin,H,W]; x_ptr/x_pad describe its halo buffer.
+    Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape."""
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = weight.shape
+    lib = _lib.load()
+    d = ConvDesc(_code(dtype), B, H, W, Cin, Cout, k, stride, x_pad, 1)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M = B * OH * OW
+    dev = x.device
+    wf, wd = packed_weights(weight, d, dtype)
+    y = torch.empty((M, Cout), dtype=dtype, device=dev)
+    scale = torch.empty(Cout, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = rstd = None
+    if training:
+        nblk = lib.fva_conv_stat_blocks(C.byref(d))
+        stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+        mean = torch.empty_like(scale)
+        rstd = torch.empty_like(scale)
+        _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                  bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+    else:
+        _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), C.c_void_p(0), _stream())
+        _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
+    zbuf, z = halo_alloc(B, Cout, OH, OW, dtype, dev, 1)
+    rp, rpad = (C.c_void_p(residual[0]), residual[1]) if residual is not None else (C.c_void_p(0), 0)
+    _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
+    s = None
+    if need_ctx:
+        s = _Saved()
+        s.d, s.x, s.x_ptr, s.y, s.scale, s.shift, s.mean, s.rstd, s.wd = d, x, x_ptr, y, scale, shift, mean, rstd, wd
+        s.gamma, s.dtype, s.OH, s.OW, s.M, s.wshape = gamma, dtype, OH, OW, M, tuple(weight.shape)
+        s.training = training
+    return z, s
+
+
+def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
+    """Backward of conv_block_fwd given dz (dense NHWC, dtype).  Returns (dx_buf or None, dw, dgamma, dbeta)."""
+    if not s.training:
+        raise RuntimeError('fastvision_amd: backward through an eval-mode BatchNorm block is not supported')
+    lib = _lib.load()
+    d, dtype, dev = s.d, s.dtype, s.y.device
+    Cout, code = d.Cout, _code(s.dtype)
+    nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
+    part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+    _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+              _p(part), nb, s.M, Cout, _stream())
+    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+    _lib.call('fva_bn_bwd_finalize', _p(part), nb, s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+    dy = torch.empty((d.B, s.OH + 2, s.OW + 2, Cout), dtype=dtype, device=dev)
+    _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+              _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+    dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
+    ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+    dx = None
+    if need_dx:
+        dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
+        _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(s.wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
+    return dx, dw, dgamma, dbeta
+
+
+def _grad_like(dx_buf, x):
+    """dense NHWC gradient buffer -> tensor shaped and typed like the forward input x."""
+    g = dense_view(dx_buf)
+    return g if g.dtype == x.dtype else g.to(x.dtype)
+
+
+class ConvBNSiLUFn(torch.autograd.Function):
+    """One ConvBlock3x3 / ConvBlock1x1 (reference classfication/models/darknet53.py:22-44)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, training, stride, dtype):
+        require_gpu(x, 'ConvBlock')
+        keep, x_ptr, x_pad = to_halo(x, dtype, weight.shape[2] // 2)
+        need = any(ctx.needs_input_grad)
+        z, s = conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, need_ctx=need)
+        if s is not None:
+            s.keep = keep
+        ctx.s = s
+        ctx.x_like = x
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        s = ctx.s
+        keep, dz_ptr = to_dense(dz, s.dtype)
+        dx, dw, dg, db = conv_block_bwd(s, dz_ptr, ctx.needs_input_grad[0])
+        return (_grad_like(dx, ctx.x_like) if dx is not None else None), dw, dg, db, None, None, None, None
+
+
+class StemFn(torch.autograd.Function):
+    """conv0 of Darknet-53 on the caller's fp32 NCHW images (darknet53.py:73) + BN + SiLU."""
+
+    @staticmethod
+    def forward(ctx, images, weight, gamma, beta, bn, training, dtype):
+        require_gpu(images, 'stem')
+        img = images.detach()
+        if img.dtype != torch.float32 or not img.is_contiguous():
+            img = img.float().contiguous()
+        B, Cin, H, W = img.shape
+        Cout = weight.shape[0]
+        lib = _lib.load()
+        dev, code = img.device, _code(dtype)
+        M = B * H * W
+        y = torch.empty((M, Cout), dtype=dtype, device=dev)
+        scale = torch.empty(Cout, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        mean = rstd = None
+        if training:
+            nblk = lib.fva_stem_stat_blocks(B, H, W)
+            stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
+            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), _p(stats), B, Cin, H, W, Cout, _stream())
+            mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
+            _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                      bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+        else:
+            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), C.c_void_p(0), B, Cin, H, W, Cout, _stream())
+            _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
+        zbuf, z = halo_alloc(B, Cout, H, W, dtype, dev, 1)
+        _lib.call('fva_bn_silu_apply', code, _p(y), _p(scale), _p(shift), C.c_void_p(0), 0, _p(zbuf), 1, B, H, W, Cout, _stream())
+        ctx.saved = (img, y, scale, shift, mean, rstd, gamma, dtype, training, tuple(weight.shape))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        img, y, scale, shift, mean, rstd, gamma, dtype, training, wshape = ctx.saved
+        if not training:
+            raise RuntimeError('fastvision_amd: backward through an eval-mode BatchNorm block is not supported')
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('fastvision_amd: the stem does not produce a gradient for the input images')
+        lib = _lib.load()
+        B, Cin, H, W = img.shape
+        Cout, code, dev = wshape[0], _code(dtype), img.device
+        M = B * H * W
+        keep, dz_ptr = to_dense(dz, dtype)
+        nb = lib.fva_bn_bwd_blocks(code, M, Cout)
+        part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(part),
+                  nb, M, Cout, _stream())
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_bn_bwd_finalize', _p(part), nb, M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+        dy = torch.empty((M, Cout), dtype=dtype, device=dev)
+        _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
+                  _p(dy), 0, B, H, W, Cout, _stream())
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+        wsb = lib.fva_stem_wgrad_workspace(B, Cin, H, W, Cout)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call('fva_stem_wgrad', code, _p(img), _p(dy), _p(dw), 0, _p(ws), wsb, B, Cin, H, W, Cout, _stream())
+        return None, dw, dgamma, dbeta, None, None, None
+
+
+class ResidualFn(torch.autograd.Function):
+    """x + CB3x3(CB1x1(x)) as one node (darknet53.py:46-63): the add is fused into the second block's
+    apply pass, its gradient sum into the first block's dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, bn1, w2, g2, b2, bn2, training, dtype):
+        require_gpu(x, 'ResidualBlock')
+        keep, x_ptr, x_pad = to_halo(x, dtype, 1)
+        need = any(ctx.needs_input_grad)
+        z1, s1 = conv_block_fwd(x, x_ptr, x_pad, w1, g1, b1, bn1, training, 1, dtype, need_ctx=need)
+        z1_ptr, z1_pad = halo_info(z1, dtype)
+        z2, s2 = conv_block_fwd(z1, z1_ptr, z1_pad, w2, g2, b2, bn2, training, 1, dtype, residual=(x_ptr, x_pad), need_ctx=need)
+        if need:
+            s1.keep = keep
+        ctx.s1, ctx.s2, ctx.x_like = s1, s2, x
+        return z2
+
+    @staticmethod
+    def backward(ctx, dout):
+        s1, s2 = ctx.s1, ctx.s2
+        keep, dout_ptr = to_dense(dout, s1.dtype)
+        dz1, dw2, dg2, db2 = conv_block_bwd(s2, dout_ptr, True)
+        dx, dw1, dg1, db1 = conv_block_bwd(s1, dz1.data_ptr(), ctx.needs_input_grad[0], addend_ptr=dout_ptr)
+        gx = _grad_like(dx, ctx.x_like) if dx is not None else None
+        return gx, dw1, dg1, db1, None, dw2, dg2, db2, None, None, None
+
+
+class UpsampleConcatFn(torch.autograd.Function):
+    """cat(upsample2(up), skip) (library order, yolov3neck.py:105,110) or cat(skip, upsample2(up)) (demo order)."""
+
+    @staticmethod
+    def forward(ctx, up, skip, up_first, dtype):
+        require_gpu(up, 'UpSampling')
+        ku, up_ptr, up_pad = to_halo(up, dtype, 0)
+        ks, sk_ptr, sk_pad = to_halo(skip, dtype, 0)
+        B, Cup, h, w = up.shape
+        Cs = skip.shape[1]
+        if tuple(skip.shape) != (B, Cs, 2 * h, 2 * w):
+            raise RuntimeError(f'upsample/concat: skip {tuple(skip.shape)} does not match 2x of {tuple(up.shape)}')
+        buf, out = halo_alloc(B, Cup + Cs, 2 * h, 2 * w, dtype, up.device, 1)
+        _lib.call('fva_upsample2_concat_fwd', _code(dtype), C.c_void_p(up_ptr), up_pad, C.c_void_p(sk_ptr), sk_pad, _p(buf),
+                  B, h, w, Cup, Cs, 1 if up_first else 0, _stream())
+        ctx.meta = (B, h, w, Cup, Cs, up_first, dtype, up.dtype, skip.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        B, h, w, Cup, Cs, up_first, dtype, udt, sdt = ctx.meta
+        keep, dptr = to_dense(dcat, dtype)
+        dup = torch.empty((B, h, w, Cup), dtype=dtype, device=dcat.device)
+        dsk = torch.empty((B, 2 * h, 2 * w, Cs), dtype=dtype, device=dcat.device)
+        _lib.call('fva_upsample2_concat_bwd', _code(dtype), C.c_void_p(dptr), _p(dup), _p(dsk), B, h, w, Cup, Cs,
+                  1 if up_first else 0, _stream())
+        gu, gs = dense_view(dup), dense_view(dsk)
+        return (gu if gu.dtype == udt else gu.to(udt)), (gs if gs.dtype == sdt else gs.to(sdt)), None, None
+
+
+NPAD = 256  # head channels (255) padded for the MFMA backward kernels
+
+
+class HeadFn(torch.autograd.Function):
+    """Biased 1x1 conv to A*(5+C) channels (yolov3head.py:50,60).  Returns the fp32 buffer [B,H,W,N]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype):
+        require_gpu(x, 'head')
+        keep, x_ptr, x_pad = to_halo(x, dtype, 0)
+        B, Cin, H, W = x.shape
+        N = weight.shape[0]
+        d = ConvDesc(_code(dtype), B, H, W, Cin, N, 1, 1, x_pad, 1)
+        wf, _ = packed_weights(weight, d, dtype)
+        out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+        _lib.call('fva_head_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(bias), _p(out), _stream())
+        ctx.saved = (keep, x_ptr, x_pad, weight, dtype, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        keep, x_ptr, x_pad, weight, dtype, x_like = ctx.saved
+        lib = _lib.load()
+        B, Cin, H, W = x_like.shape
+        N = weight.shape[0]
+        npad = (N + 63) // 64 * 64
+        dev, code = dout.device, _code(dtype)
+        if dout.dtype != torch.float32 or not dout.is_contiguous():
+            dout = dout.float().contiguous()
+        dy = torch.empty((B, H + 2, W + 2, npad), dtype=dtype, device=dev)
+        dbias = torch.empty(N, dtype=torch.float32, device=dev)
+        ws = torch.empty(1024 * N, dtype=torch.float32, device=dev)
+        _lib.call('fva_head_bwd_prepare', code, _p(dout), C.c_void_p(0), _p(dy), _p(dbias), 0, _p(ws), B, H, W, N, npad, _stream())
+        # weight padded to npad rows so that dgrad / wgrad run as an ordinary Cout = npad convolution
+        wpad = torch.zeros((npad, Cin, 1, 1), dtype=torch.float32, device=dev)
+        wpad[:N].copy_(weight.detach())
+        d = ConvDesc(code, B, H, W, Cin, npad, 1, 1, x_pad, 1)
+        _, wd = packed_weights(wpad, d, dtype, cache=False)
+        dwp = torch.empty((npad, Cin, 1, 1), dtype=torch.float32, device=dev)
+        wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
+        wsw = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(x_ptr), _p(dy), _p(dwp), 0, _p(wsw), wsb, _stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxb = torch.empty((B, H, W, Cin), dtype=dtype, device=dev)
+            _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dxb), C.c_void_p(0), _stream())
+            dx = _grad_like(dxb, x_like)
+        return dx, dwp[:N].contiguous(), dbias, None
+
+
+# ------------------------------------------------------------------------------------------------ thin functional API
+def conv_bn_silu(x, conv, bn, stride=None, dtype=None):
+    dtype = dtype or get_compute_dtype()
+    stride = conv.stride[0] if stride is None else stride
+    return ConvBNSiLUFn.apply(x, conv.weight, bn.weight, bn.bias, _BNState(bn), bn.training, stride, dtype)
+
+
+def stem(images, conv, bn, dtype=None):
+    dtype = dtype or get_compute_dtype()
+    return StemFn.apply(images, conv.weight, bn.weight, bn.bias, _BNState(bn), bn.training, dtype)
+
+
+def residual(x, cb1, cb2, dtype=None):
+    dtype = dtype or get_compute_dtype()
+    return ResidualFn.apply(x, cb1.conv.weight, cb1.bn.weight, cb1.bn.bias, _BNState(cb1.bn),
+                            cb2.conv.weight, cb2.bn.weight, cb2.bn.bias, _BNState(cb2.bn), cb1.bn.training, dtype)
+
+
+def upsample2_concat(up, skip, up_first, dtype=None):
+    return UpsampleConcatFn.apply(up, skip, up_first, dtype or get_compute_dtype())
+
+
+def head_conv(x, conv, dtype=None):
+    return HeadFn.apply(x, conv.weight, conv.bias, dtype or get_compute_dtype())

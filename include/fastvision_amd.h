@@ -69,8 +69,9 @@ int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad);
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
 int32_t fva_conv_stat_blocks(const fva_conv_desc* d);
 
-/* dx[B][H][W][Cin] (dense, dtype) (+)= conv_transpose(dy, w).  dy is halo NHWC with border d->dy_pad. */
-int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate, void* stream);
+/* dx[B][H][W][Cin] (dense, dtype) = conv_transpose(dy, w) (+ addend).  dy is halo NHWC with border d->dy_pad.
+ * addend (optional, dense like dx, may alias dx) is added in the epilogue: the residual-branch gradient sum. */
+int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream);
 
 /* dw (fp32, OIHW) (+)= sum_pixels dy x.  Deterministic: split-K partial tiles go to `workspace`
  * (fva_conv_wgrad_workspace() bytes) and are reduced in fixed order. */
@@ -91,21 +92,23 @@ int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
  * demos/yolov3_u/models/yolov3.py:119-135).  Output fp32, dense [B*H*W][N] (pixel-major, N contiguous):
  * the library's permuted [B,A,H,W,5+C] (yolov3head.py:63) and the demo's NCHW are strided views of it. */
 int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream);
-/* dhead fp32 [M][N] * (*grad_scale, device scalar, may be NULL = 1) -> dy dtype [M][Npad] (Npad = N rounded
- * up to 64, pad columns zero) and dbias[N] (+)= column sums. */
+/* dhead fp32 [B*H*W][N] * (*grad_scale, device scalar, may be NULL = 1) -> dy (dtype) as a halo buffer
+ * [B][H+2][W+2][Npad] (border 1, pad columns N..Npad-1 zero) ready for fva_conv_dgrad / fva_conv_wgrad with
+ * Cout = Npad, and dbias[N] (+)= column sums (deterministic two-stage reduce; workspace >= 4*N*1024 bytes). */
 int fva_head_bwd_prepare(int dtype, const float* dhead, const float* grad_scale, void* dy, float* dbias,
-                         int accumulate, int64_t M, int N, int Npad, void* stream);
+                         int accumulate, void* workspace, int B, int H, int W, int N, int Npad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (training + eval) fused with SiLU and the residual add.  Replaces nn.BatchNorm2d +
- * nn.SiLU (+ `identity + conv2`) in ConvBlock*/ResidualBlock (darknet53.py:11-17,28-31,58-62).
+ * nn.SiLU (+ `identity + conv2`) in ConvBlock3x3 / ConvBlock1x1 / ResidualBlock (darknet53.py:11-17,28-31,58-62).
  * ---------------------------------------------------------------------------------------------- */
-/* Reduce conv partial stats -> batch mean / biased var; update running stats (momentum, unbiased var);
- * emit save_mean, save_rstd and the fused scale = gamma*rstd, shift = beta - mean*scale. */
+/* Reduce conv partial stats -> batch mean / biased var; update running stats (momentum, unbiased var) and
+ * num_batches_tracked += 1 (both optional: NULL skips); emit save_mean, save_rstd and the fused
+ * scale = gamma*rstd, shift = beta - mean*scale. */
 int fva_bn_finalize(const float* stats_partial, int32_t nblocks, int64_t count, int32_t C,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
-                    float momentum, float eps, float* save_mean, float* save_rstd, float* scale, float* shift,
-                    void* stream);
+                    int64_t* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_rstd,
+                    float* scale, float* shift, void* stream);
 /* Eval mode: scale/shift from running stats. */
 int fva_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -117,7 +120,7 @@ int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float*
 int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
                            const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks,
                            int64_t M, int C, void* stream);
-int32_t fva_bn_bwd_blocks(int64_t M, int C);
+int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
 /* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2. */
 int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
                         const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
@@ -172,7 +175,8 @@ int fva_yolov3_match(const float* targets, int32_t T, const fva_head_level* leve
 
 /* Loss forward + analytic backward for all levels in one call (yolov3_loss.py:29-72).
  * loss_out[4] = {total, box, conf, cls} (total already * ratios * B); grads (if level.grad != NULL) are
- * d total / d head, written for EVERY element (zeros included).  workspace: fva_yolov3_loss_workspace(). */
+ * d total / d head ACCUMULATED into level.grad, which the caller zero-fills first (the objectness channel
+ * of every cell is stored, matched rows are added).  workspace: fva_yolov3_loss_workspace(). */
 int fva_yolov3_loss(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels,
                     float ratio_box, float ratio_conf, float ratio_cls, float* loss_out,
                     void* workspace, int64_t workspace_bytes, void* stream);
@@ -187,8 +191,10 @@ int64_t fva_demo_loss_workspace(int32_t T, const fva_head_level* levels, int32_t
 
 /* IoU family on device (detection/tools/IOU.py, BOX.py).  kind: 0 IoU 1 GIoU 2 DIoU 3 CIoU;
  * mode: 0 xyxy 1 xywh 2 wh; variant: 0 library 1 demo (iou.py centre sums / minus sign).
- * pairwise: out[N]; batch: out[N][M]. */
-int fva_iou_pairwise(int kind, int mode, int variant, const float* a, const float* b, float* out, int64_t N, float eps, void* stream);
+ * pairwise: out[N] and (optional) grad_a[N][4 or 2] = d out / d a in the caller's box parametrisation (ties
+ * split as torch.maximum/minimum do, CIoU alpha constant); batch: out[N][M]. */
+int fva_iou_pairwise(int kind, int mode, int variant, const float* a, const float* b, float* out, float* grad_a, int64_t N,
+                     float eps, void* stream);
 int fva_iou_batch(int kind, int mode, int variant, const float* a, const float* b, float* out, int64_t N, int64_t M, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

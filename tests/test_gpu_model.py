@@ -1,0 +1,299 @@
+"""GPU parity tests, path level: matcher / losses / whole model / 100-step curve against the golden vectors
+captured from the reference (tests/golden) and against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): anchor/target indexing bit-exact; fp32 loss and gradients within 1e-3 relative; the
+100-step loss curve within 1e-3 of the CPU reference.  bf16 results are reported with their own (looser)
+tolerance, stated in each test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fastvision_amd.synthetic import coco_anchors_feature, coco_anchors_px, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def stats(t):
+    t = t.detach().double().flatten().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item()] + t[:4].tolist() + [0.0] * max(0, 4 - t.numel()))
+
+
+def assert_stats_close(got, want, rel, what=''):
+    scale = np.maximum(want[:, 1:2], 1e-30)
+    bad = np.abs(got[:, 0:1] - want[:, 0:1]) / scale
+    assert bad.max() < rel, f'{what} sum mismatch {bad.max()} at row {bad.argmax()}'
+    r = np.abs(got[:, 1] - want[:, 1]) / np.maximum(want[:, 1], 1e-12)
+    assert r.max() < rel, f'{what} abs-sum mismatch {r.max()} at row {r.argmax()}'
+
+
+def lib_model(seed=20220504, training=True):
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    torch.manual_seed(seed)
+    m = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+               in_channels=3, num_classes=80, training=training)
+    return m.to(DEV).train(training)
+
+
+class _Shell:
+    def __init__(self):
+        self.anchors_per_level = [a for a in coco_anchors_px().view(3, 3, 1, 1, 2)]
+        self.backbone_strides_per_level = [32, 16, 8]
+
+
+def lib_loss():
+    from fastvision_amd.loss import Yolov3Loss
+    return Yolov3Loss(_Shell(), 0.5, 0.05, 1.0, 0.5)
+
+
+# ------------------------------------------------------------------------------------------------ G1 matcher, bit-exact
+def _check_match(gold, prefix, grids_hw, batch):
+    crit = lib_loss()
+    tg = T(gold[f'{prefix}_targets']).to(DEV)
+    shapes = [torch.empty((batch, 3, h, w, 0), device=DEV) for h, w in grids_hw]
+    locs, cats, xywh, anc = crit.build_target(shapes, tg)
+    for l in range(3):
+        assert np.array_equal(locs[l][0].cpu().numpy(), gold[f'{prefix}_l{l}_b'])
+        assert np.array_equal(locs[l][1].cpu().numpy(), gold[f'{prefix}_l{l}_gxy'])
+        assert np.array_equal(locs[l][2].cpu().numpy(), gold[f'{prefix}_l{l}_a'])
+        assert np.array_equal(cats[l].cpu().numpy(), gold[f'{prefix}_l{l}_cls'])
+        assert np.array_equal(xywh[l].cpu().numpy(), gold[f'{prefix}_l{l}_xywh'])     # fp32 outputs are bit-exact too
+        assert np.array_equal(anc[l].cpu().numpy(), gold[f'{prefix}_l{l}_anc'])
+
+
+def test_matcher_bit_exact_vs_reference(gold_lib):
+    for c in range(int(gold_lib['g1_cases'])):
+        grids = gold_lib[f'g1_{c}_grids']
+        _check_match(gold_lib, f'g1_{c}', [(int(s), int(s)) for s in grids], 8)
+    _check_match(gold_lib, 'g1ns', [(20, 15), (40, 30), (80, 60)], 2)
+
+
+def test_matcher_full_size_properties():
+    """BASELINE config 3 sizes (B=32, 640 px): counts and index ranges agree with the oracle run on the same batch."""
+    from oracle import losses as ol, model as om
+    _, tg = synthetic_batch(32, 640)
+    crit = lib_loss()
+    shapes = [torch.empty((32, 3, g, g, 0), device=DEV) for g in (20, 40, 80)]
+    locs, cats, xywh, anc = crit.build_target(shapes, tg.to(DEV))
+    ref = ol.build_target([(32, 3, g, g, 85) for g in (20, 40, 80)], tg, [a for a in om.coco_anchors_px().view(3, 3, 1, 1, 2)],
+                          om.LEVEL_STRIDES)
+    for l, g in enumerate((20, 40, 80)):
+        assert torch.equal(locs[l][0].cpu(), ref[0][l][0]) and torch.equal(locs[l][1].cpu(), ref[0][l][1])
+        assert torch.equal(locs[l][2].cpu(), ref[0][l][2]) and torch.equal(cats[l].cpu(), ref[1][l])
+        assert torch.equal(xywh[l].cpu(), ref[2][l]) and torch.equal(anc[l].cpu(), ref[3][l])
+        assert int(locs[l][1].max()) < g and int(locs[l][1].min()) >= 0
+
+
+# ------------------------------------------------------------------------------------------------ G2 IoU family
+def test_iou_family_vs_reference(gold_lib, gold_demo):
+    from fastvision_amd.demos.yolov3_u.utils import iou as DI
+    from fastvision_amd.detection import tools as TT
+    a, b = T(gold_lib['g2_a']).to(DEV), T(gold_lib['g2_b']).to(DEV)
+    wa, wb = a[:, 2:] - a[:, :2], b[:, 2:] - b[:, :2]
+    xa, xb = TT.xyxy2xywh(a), TT.xyxy2xywh(b)
+    chk = lambda got, key: np.testing.assert_allclose(got.cpu().numpy(), gold_lib[key], rtol=2e-5, atol=2e-6)
+    chk(TT.xyxy_iou(a, b), 'g2_xyxy_iou')
+    chk(TT.xywh_iou(xa, xb), 'g2_xywh_iou')
+    chk(TT.wh_iou(wa, wb), 'g2_wh_iou')
+    chk(TT.xyxy_iou_batch(a[:40], b[:24]), 'g2_xyxy_iou_batch')
+    chk(TT.xywh_iou_batch(xa[:40], xb[:24]), 'g2_xywh_iou_batch')
+    chk(TT.wh_iou_batch(wa[:40], wb[:24]), 'g2_wh_iou_batch')
+    chk(TT.GIOU(a, b), 'g2_giou')
+    chk(TT.DIOU(a, b), 'g2_diou')
+    chk(TT.CIOU(a, b), 'g2_ciou')
+    chk(TT.CIOU(xa, xb, mode='xywh'), 'g2_ciou_xywh')
+    a2, b2 = T(gold_demo['g2_a']).to(DEV), T(gold_demo['g2_b']).to(DEV)
+    np.testing.assert_allclose(DI.DIOU(a2, b2).cpu().numpy(), gold_demo['g2_diou'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(DI.CIOU(a2, b2).cpu().numpy(), gold_demo['g2_ciou'], rtol=2e-5, atol=2e-6)
+    # CIOULoss value and gradient w.r.t. the predicted boxes
+    from fastvision_amd.loss import CIOULoss
+    ar = a.clone().requires_grad_(True)
+    l = CIOULoss('mean')(ar, b)
+    np.testing.assert_allclose(l.detach().cpu().numpy().reshape(1), gold_lib['g2_cioul'], rtol=1e-5)
+    l.backward()
+    np.testing.assert_allclose(ar.grad.cpu().numpy(), gold_lib['g2_cioul_grad'], rtol=1e-3, atol=1e-6)
+    with pytest.raises(Exception):
+        TT.cal_iou(a, b, mode='nope')
+    with pytest.raises(RuntimeError):
+        TT.xyxy_iou(a.cpu(), b.cpu())
+
+
+# ------------------------------------------------------------------------------------------------ G3 losses + head grads
+@pytest.mark.parametrize('tag', ['rand', 'empty', 'dup', 'syn'])
+def test_library_loss_and_head_grads_vs_reference(gold_lib, tag):
+    crit = lib_loss()
+    tg = T(gold_lib[f'g3_{tag}_targets']).to(DEV)
+    heads = [T(gold_lib[f'g3_{tag}_head{l}']).to(DEV).requires_grad_(True) for l in range(3)]
+    loss = crit(heads, tg)
+    assert tuple(loss.shape) == (1,)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), gold_lib[f'g3_{tag}_loss'], rtol=1e-4)
+    loss.backward()
+    for l in range(3):
+        want = gold_lib[f'g3_{tag}_grad{l}']
+        got = heads[l].grad.cpu().numpy()
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-12)
+        assert err < 1e-3, f'{tag} level {l}: {err}'
+
+
+@pytest.mark.parametrize('tag', ['syn', 'syn4', 'dup'])
+def test_demo_loss_and_head_grads_vs_reference(gold_demo, tag):
+    from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+
+    class M:
+        anchors = coco_anchors_feature()
+    crit = ComputeLoss()
+    tg = T(gold_demo[f'g3_{tag}_targets']).to(DEV)
+    heads = [T(gold_demo[f'g3_{tag}_head{l}']).to(DEV).requires_grad_(True) for l in range(3)]
+    loss = crit(heads, tg, M())
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), gold_demo[f'g3_{tag}_loss'], rtol=1e-4)
+    np.testing.assert_allclose(crit.last_parts.cpu().numpy(), gold_demo[f'g3_{tag}_parts'], rtol=1e-4)
+    loss.backward()
+    for l in range(3):
+        want = gold_demo[f'g3_{tag}_grad{l}']
+        err = np.abs(heads[l].grad.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-12)
+        assert err < 1e-3, f'{tag} level {l}: {err}'
+
+
+# ------------------------------------------------------------------------------------------------ G5 whole model, fp32
+def test_library_model_fp32_vs_reference(gold_lib):
+    import fastvision_amd
+    with fastvision_amd.compute_dtype(torch.float32):
+        net = lib_model()
+        crit = lib_loss()
+        images, tg = synthetic_batch(2, 64)
+        pred = net(images.to(DEV))
+        for l, h in enumerate(pred):
+            want = gold_lib[f'g5_head{l}']
+            assert tuple(h.shape) == want.shape
+            err = np.abs(h.detach().cpu().numpy() - want).max() / np.abs(want).max()
+            assert err < 1e-3, f'head {l}: {err}'
+        loss = crit(pred, tg.to(DEV))
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), gold_lib['g5_loss'], rtol=1e-3)
+        loss.backward()
+    assert [k for k, _ in net.named_parameters()] == list(gold_lib['g5_gradkeys'])
+    grads = np.stack([stats(p.grad) for _, p in net.named_parameters()])
+    assert_stats_close(grads, gold_lib['g5_grads'], 2e-3, 'grads')
+    after = np.stack([stats(v.float()) for v in net.state_dict().values()])
+    assert_stats_close(after, gold_lib['g5_after'], 1e-3, 'state after step')
+
+
+def test_library_eval_decode_vs_reference(gold_lib):
+    import fastvision_amd
+    with fastvision_amd.compute_dtype(torch.float32):
+        net = lib_model()
+        images, _ = synthetic_batch(2, 64)
+        net(images.to(DEV))                          # one train-mode forward updates the running stats as in the fixture
+        net.eval()
+        with torch.no_grad():
+            heads, dec = net(images.to(DEV), val=True)
+    want = gold_lib['g5_decode']
+    assert tuple(dec.shape) == want.shape
+    err = np.abs(dec.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 2e-3, err
+
+
+def test_demo_model_fp32_vs_reference(gold_demo):
+    import fastvision_amd
+    from fastvision_amd.demos.yolov3_u.models import YoloV3
+    from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+    with fastvision_amd.compute_dtype(torch.float32):
+        torch.manual_seed(20220504)
+        net = YoloV3(anchors=coco_anchors_feature()).to(DEV).train()
+        crit = ComputeLoss()
+        images, tg = synthetic_batch(2, 64)
+        pred = net(images.to(DEV))
+        for l, h in enumerate(pred):
+            want = gold_demo[f'g5_head{l}']
+            assert tuple(h.shape) == want.shape
+            err = np.abs(h.detach().cpu().numpy() - want).max() / np.abs(want).max()
+            assert err < 1e-3, f'head {l}: {err}'
+        loss = crit(pred, tg.to(DEV), net)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), gold_demo['g5_loss'], rtol=1e-3)
+        loss.backward()
+    grads = np.stack([stats(p.grad) for _, p in net.named_parameters()])
+    assert_stats_close(grads, gold_demo['g5_grads'], 2e-3, 'grads')
+
+
+# ------------------------------------------------------------------------------------------------ G6 100-step loss curve
+@pytest.mark.parametrize('surface', ['lib', 'demo'])
+def test_loss_curve_100_steps_fp32_vs_reference(gold_lib, gold_demo, surface):
+    import fastvision_amd
+    from fastvision_amd import FusedAdam
+    images, tg = synthetic_batch(2, 128)
+    images, tg = images.to(DEV), tg.to(DEV)
+    with fastvision_amd.compute_dtype(torch.float32):
+        if surface == 'lib':
+            net, crit, gold = lib_model(), lib_loss(), gold_lib['g6_curve']
+            step_loss = lambda pred: crit(pred, tg)
+        else:
+            from fastvision_amd.demos.yolov3_u.models import YoloV3
+            from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+            torch.manual_seed(20220504)
+            net = YoloV3(anchors=coco_anchors_feature()).to(DEV).train()
+            cl, gold = ComputeLoss(), gold_demo['g6_curve']
+            step_loss = lambda pred: cl(pred, tg, net)
+        opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+        curve = []
+        for _ in range(100):
+            pred = net(images)
+            opt.zero_grad()
+            loss = step_loss(pred)
+            loss.backward()
+            opt.step()
+            curve.append(loss.detach())
+    curve = torch.cat(curve).cpu().numpy()
+    rel = np.abs(curve - gold) / np.abs(gold)
+    print(f'{surface} curve: first {curve[:3]} last {curve[-3:]} max rel dev {rel.max():.2e} at step {rel.argmax()}')
+    assert rel.max() < 1e-3, f'{surface}: max rel deviation {rel.max()} at step {rel.argmax()}'
+
+
+# ------------------------------------------------------------------------------------------------ bf16 path (the bench dtype)
+def test_library_model_bf16_close_to_fp32_reference(gold_lib):
+    """bf16 storage / fp32 accumulate: heads within 3e-2 of the fp32 reference's scale, loss within 2e-2."""
+    import fastvision_amd
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        net = lib_model()
+        crit = lib_loss()
+        images, tg = synthetic_batch(2, 64)
+        pred = net(images.to(DEV))
+        errs = []
+        for l, h in enumerate(pred):
+            want = gold_lib[f'g5_head{l}']
+            errs.append(np.abs(h.detach().cpu().numpy() - want).max() / np.abs(want).max())
+        loss = crit(pred, tg.to(DEV))
+        loss.backward()
+    lrel = abs(loss.item() - gold_lib['g5_loss'].item()) / gold_lib['g5_loss'].item()
+    print('bf16 head errs', errs, 'loss rel', lrel)
+    assert max(errs) < 3e-2 and lrel < 2e-2
+    grads = np.stack([stats(p.grad) for _, p in net.named_parameters()])
+    r = np.abs(grads[:, 1] - gold_lib['g5_grads'][:, 1]) / np.maximum(gold_lib['g5_grads'][:, 1], 1e-12)
+    print('bf16 grad abs-sum rel dev: median', np.median(r), 'max', r.max())
+    assert np.median(r) < 5e-2
+
+
+def test_full_size_step_runs_and_is_finite():
+    """One bf16 train step at reduced batch of the bench shape (B=4, 640 px): finite loss, every parameter gets a
+    finite gradient, BN buffers move -- size-independent sanity at the real spatial sizes (grids 20/40/80)."""
+    import fastvision_amd
+    from fastvision_amd import FusedAdam
+    net, crit = lib_model(), lib_loss()
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+    images, tg = synthetic_batch(4, 640)
+    pred = net(images.to(DEV))
+    assert [tuple(p.shape) for p in pred] == [(4, 3, 20, 20, 85), (4, 3, 40, 40, 85), (4, 3, 80, 80, 85)]
+    opt.zero_grad()
+    loss = crit(pred, tg.to(DEV))
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss).all()
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert int(net.backbone.conv0.bn.num_batches_tracked) == 1

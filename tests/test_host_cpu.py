@@ -1,0 +1,113 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/fastvision_amd.h declares, the host
+modules mirror the reference's state_dict keys / seeded init (checked against the pinned oracle), the product
+path refuses CPU tensors loudly, and the synthetic batch generator is deterministic.  No compute calls here."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from fastvision_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_header_symbol(built):
+    hdr = open(os.path.join(ROOT, 'include', 'fastvision_amd.h')).read()
+    declared = set(re.findall(r'\b(fva_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'fva_status', 'fva_dtype'}
+    lib = built.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in the header but not exported'
+    assert declared == set(built.PROTOTYPES), declared ^ set(built.PROTOTYPES)
+    assert lib.fva_version() >= 1
+
+
+def test_argument_errors_are_reported_not_crashed(built):
+    import ctypes as C
+    lib = built.load()
+    d = built.ConvDesc(1, 2, 8, 8, 48, 64, 3, 1, 1, 1)        # Cin=48 is not a multiple of 64 (bf16 k-tile)
+    rc = lib.fva_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None)
+    assert rc == -1 and b'reduction channels' in lib.fva_last_error()
+    d = built.ConvDesc(0, 2, 8, 8, 64, 64, 5, 1, 2, 1)
+    assert lib.fva_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None) == -1
+    with pytest.raises(RuntimeError):
+        built.call('fva_adam_step', None, None, 0, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None)
+
+
+def test_modules_mirror_reference_keys_and_seeded_init():
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.demos.yolov3_u.models import YoloV3
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.synthetic import coco_anchors_feature, coco_anchors_px
+    from oracle import train as otrain
+    torch.manual_seed(20220504)
+    net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(),
+                 num_anchors_per_level=[3, 3, 3], training=True)
+    ref, _ = otrain.make_library(20220504)
+    sd, rsd = net.state_dict(), ref.state_dict()
+    assert list(sd) == list(rsd) and len(sd) == 438
+    assert all(torch.equal(sd[k], rsd[k]) for k in sd)
+    assert net.backbone_strides_per_level == [32, 16, 8] and net.backbone_channels_per_level == [1024, 512, 256]
+    assert [tuple(a.shape) for a in net.anchors_per_level] == [(3, 1, 1, 2)] * 3
+    torch.manual_seed(20220504)
+    demo = YoloV3(anchors=coco_anchors_feature())
+    dref, _ = otrain.make_demo(20220504)
+    sd, rsd = demo.state_dict(), dref.state_dict()
+    assert list(sd) == list(rsd) and all(torch.equal(sd[k], rsd[k]) for k in sd)
+    assert list(sd)[:312] == [k for k in net.state_dict() if k.startswith('backbone.')]      # shared backbone keys
+
+
+def test_product_path_refuses_cpu_tensors():
+    from fastvision_amd.classfication.models.darknet53 import ConvBlock3x3
+    from fastvision_amd.detection.tools import xyxy_iou
+    from fastvision_amd.loss import Yolov3Loss
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ConvBlock3x3(32, 64)(torch.zeros(1, 32, 8, 8))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        xyxy_iou(torch.zeros(2, 4), torch.zeros(2, 4))
+
+    class M:
+        anchors_per_level = [torch.ones(3, 1, 1, 2)] * 3
+        backbone_strides_per_level = [32, 16, 8]
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        Yolov3Loss(M(), 0.5, 0.05, 1.0, 0.5)([torch.zeros(1, 3, 2, 2, 85)] * 3, torch.zeros(1, 6))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from fastvision_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libfastvision_amd.so')
+    with pytest.raises(RuntimeError, match='REQUIRED'):
+        _lib.load()
+
+
+def test_synthetic_batch_is_deterministic_and_well_formed():
+    from fastvision_amd.synthetic import synthetic_batch
+    a_img, a_t = synthetic_batch(4, 64)
+    b_img, b_t = synthetic_batch(4, 64)
+    assert torch.equal(a_img, b_img) and torch.equal(a_t, b_t)
+    assert a_t.shape[1] == 6 and (a_t[:, 0].diff() >= 0).all()
+    assert set(a_t[:, 0].long().tolist()) == {0, 1, 2, 3}             # every image has >= 1 box
+    assert (a_t[:, 2:4] < 1).all() and (a_t[:, 2:] > 0).all()
+    c_img, _ = synthetic_batch(4, 64, rank=1)
+    assert not torch.equal(a_img, c_img)
+
+
+def test_halo_view_detection():
+    from fastvision_amd import ops
+    buf, view = ops.halo_alloc(2, 8, 5, 6, torch.float32, 'cpu', pad=1)
+    info = ops.halo_info(view, torch.float32)
+    assert info is not None and info[1] == 1 and info[0] == buf.data_ptr()
+    dense = torch.zeros(2, 5, 6, 8).permute(0, 3, 1, 2)
+    assert ops.halo_info(dense, torch.float32)[1] == 0
+    assert ops.halo_info(torch.zeros(2, 8, 5, 6), torch.float32) is None      # plain NCHW is foreign
+    assert ops.halo_info(view, torch.bfloat16) is None
