@@ -50,7 +50,9 @@ class _DemoLossFn(torch.autograd.Function):
         out = torch.empty(5, dtype=torch.float32, device=hs[0].device)
         _lib.call('fva_demo_loss', _p(targets), T, levels, len(hs), _p(out), _p(ws), wsb, _stream())
         ctx.grads, ctx.dtypes = grads, [l.dtype for l in layers]
-        return out[0:1].clone(), out[1:5].clone()
+        parts = out[1:5].clone()
+        ctx.mark_non_differentiable(parts)
+        return out[0:1].clone(), parts
 
     @staticmethod
     def backward(ctx, gout, _gparts):

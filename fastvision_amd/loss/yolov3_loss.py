@@ -58,7 +58,9 @@ class _Yolov3LossFn(torch.autograd.Function):
         ctx.grads = grads
         ctx.dtypes = [h.dtype for h in heads]
         ctx.parts = out
-        return out[0:1].clone(), out[1:4].clone()
+        parts = out[1:4].clone()
+        ctx.mark_non_differentiable(parts)
+        return out[0:1].clone(), parts
 
     @staticmethod
     def backward(ctx, gout, _gparts):

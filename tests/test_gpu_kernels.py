@@ -184,12 +184,12 @@ def test_upsample_concat(key, up_first):
     g = torch.Generator().manual_seed(3)
     up = torch.randn(2, 64, 4, 5, generator=g)
     skip = torch.randn(2, 32, 8, 10, generator=g)
-    upr, skr = rounded(up, key).requires_grad_(True), rounded(skip, key).requires_grad_(True)
+    upr, skr = rounded(up, key).clone().requires_grad_(True), rounded(skip, key).clone().requires_grad_(True)
     u = F.interpolate(upr, scale_factor=2, mode='nearest')
     want = torch.cat([u, skr] if up_first else [skr, u], dim=1)
     gy = torch.randn(want.shape, generator=g)
     (want * rounded(gy, key)).sum().backward()
-    ug, sg = up.to(dev()).requires_grad_(True), skip.to(dev()).requires_grad_(True)
+    ug, sg = up.detach().clone().to(dev()).requires_grad_(True), skip.detach().clone().to(dev()).requires_grad_(True)
     with fastvision_amd.compute_dtype(dtype):
         got = ops.upsample2_concat(ug, sg, up_first)
     assert rel_err(got, want) < 1e-6
