@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: YOLOv3 (Darknet-53 + FPN + 3-scale head) train step, 640x640, 32 images per GPU.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+A step = forward + target assignment + yolov3_loss + backward + gradient all-reduce (N > 1) + Adam on one synthetic
+batch that is resident in HBM before the timed region.  Rank 0 prints ONE JSON line: BASELINE.json's metric
+(images/sec, whole job), plus
+  roofline     -- the dominant kernel class (MFMA implicit-GEMM convolution), algorithmic FLOPs per launch divided by
+                  its average launch duration, measured live with HIP events on the launch stream in the timed region;
+  cpu_baseline -- the CPU oracle (a port of the reference's CPU path: same model / loss / Adam / step contract of
+                  utils/fit.py:52-66) timed on this host's cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+METRIC = 'images/sec (640×640, bs=32/GPU) YOLOv3 train step, 1/2/4/8 MI355X'
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+TRAIN_GFLOP_PER_IMAGE_640 = 466.97   # fwd + dgrad (not conv0) + wgrad conv FLOPs
+
+
+def cpu_baseline(size, seconds=12.0):
+    """Time the CPU oracle on a bounded sample of the same workload (smaller batch, same image size)."""
+    from oracle import train as otrain
+    from fastvision_amd.synthetic import synthetic_batch
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    batch = 2
+    images, tg = synthetic_batch(batch, size)
+    net, crit = otrain.make_library(20220504)
+    opt = otrain.make_adam(net)
+    otrain.train_steps(net, crit, opt, images, tg, 1)                  # warm-up
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < 3 and (not times or time.perf_counter() < t_end):
+        _, t = otrain.train_steps(net, crit, opt, images, tg, 1)
+        times.append(t[0])
+    med = sorted(times)[len(times) // 2]
+    return {'value': batch / med, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'CPU oracle (port of the reference CPU path), fp32, 1 warm-up + {len(times)} timed steps of '
+                      f'{batch}x3x{size}x{size}, median {med:.2f} s/step, torch threads = {cores}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--surface', default='lib', choices=['lib', 'demo'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shapes', action='store_true', help='also print per-layer-shape conv timings to stderr')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import fastvision_amd
+    from fastvision_amd import FusedAdam, parallel
+    from fastvision_amd.profiler import KernelTimer
+    from fastvision_amd.synthetic import coco_anchors_feature, coco_anchors_px, synthetic_batch
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    fastvision_amd.set_compute_dtype(dtype)
+
+    torch.manual_seed(20220504)
+    if args.surface == 'lib':
+        from fastvision_amd.classfication.models import darknet53
+        from fastvision_amd.detection.head import yolov3head
+        from fastvision_amd.detection.models import yolov3
+        from fastvision_amd.detection.neck import yolov3neck
+        from fastvision_amd.loss import Yolov3Loss
+        net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(),
+                     num_anchors_per_level=[3, 3, 3], in_channels=3, num_classes=80, training=True).to(dev).train()
+        crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+        loss_fn = lambda pred, tg: crit(pred, tg)
+    else:
+        from fastvision_amd.demos.yolov3_u.models import YoloV3
+        from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+        net = YoloV3(anchors=tuple(a.to(dev) for a in coco_anchors_feature())).to(dev).train()
+        cl = ComputeLoss()
+        loss_fn = lambda pred, tg: cl(pred, tg, net)
+    parallel.broadcast_parameters(net)
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+    reducer = parallel.GradientReducer(net.parameters()) if world > 1 else None
+
+    images, targets = synthetic_batch(args.batch, args.size, rank=rank)     # per-rank shard of the global batch (weak scaling)
+    images, targets = images.to(dev), targets.to(dev)
+
+    def step():
+        pred = net(images)
+        opt.zero_grad()
+        loss = loss_fn(pred, targets)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    with KernelTimer() as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+
+    if rank == 0:
+        summ = kt.summary()
+        ms_step = elapsed / args.steps * 1e3
+        ips = args.batch * world * args.steps / elapsed
+        peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
+        dom = max(summ, key=lambda k: summ[k]['ms_total'])
+        d = summ[dom]
+        kernel_name = {'conv_fwd': 'igemm_kernel<EPI_STATS> (fva_conv_fwd)', 'conv_dgrad': 'igemm_kernel<EPI_PLAIN> (fva_conv_dgrad)',
+                       'conv_wgrad': 'wgrad_kernel (+reduce) (fva_conv_wgrad)'}[dom]
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        out = {
+            'metric': METRIC, 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'YOLOv3 Darknet-53 {args.batch}x3x{args.size}x{args.size}/GPU {args.dtype} train step '
+                                   '(fwd + target assignment + yolov3_loss + bwd + grad all-reduce + Adam), COCO-80, random init',
+                       'surface': args.surface, 'global_batch': args.batch * world, 'image_size': args.size,
+                       'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': kernel_name, 'achieved': round(d['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(d['tflops'] / peak, 4), 'traffic': traffic, 'launches_per_step': d['launches'] // args.steps,
+                         'avg_launch_ms': round(d['ms_avg'], 4), 'gflop_per_launch': round(d['flop_per_launch'] / 1e9, 3),
+                         'ms_per_step': round(d['ms_total'] / args.steps, 3)},
+            'kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / args.steps, 3),
+                            'launches_per_step': v['launches'] // args.steps} for k, v in summ.items()},
+            'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
+            'loss': round(final_loss, 5),
+        }
+        if args.shapes:
+            for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):
+                print(f'{k}: launches {v[0]} ms_total {v[1]:.3f} tflops {v[2]:.1f}', file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -91,10 +91,18 @@ def load():
     return lib
 
 
+tracer = None   # set by fastvision_amd.profiler.KernelTimer: callable(name, args) -> context manager or None
+
+
 def call(name, *args):
     """Call a status-returning entry point; raise RuntimeError(fva_last_error()) on failure."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    span = tracer(name, args) if tracer is not None else None
+    if span is not None:
+        with span:
+            rc = getattr(lib, name)(*args)
+    else:
+        rc = getattr(lib, name)(*args)
     if name not in UNCHECKED and rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib.fva_last_error().decode()}')
     return rc

@@ -1,0 +1,150 @@
+"""Data parallelism for the hot path: one process per GPU, gradients all-reduced over RCCL/xGMI in buckets that
+are launched while the backward pass is still running.
+
+The reference only has single-process ``nn.DataParallel`` (demos/yolov3_u/train.py:85), which re-broadcasts the
+248 MB of parameters and gathers outputs to GPU 0 every step.  This replacement keeps its *semantics* where they
+matter -- per-GPU BatchNorm statistics (no SyncBN), replicated parameters -- and changes the mechanics: each rank
+computes the loss on its own 32 images and the 61.9 M gradients are averaged by one bucketed all-reduce
+(DDP semantics; the difference from DataParallel's loss-over-the-gathered-batch is documented in DESIGN.md).
+
+xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound by one link: buckets are kept large
+(default 32 MiB, ~8 buckets) to amortise latency, and are filled in reverse registration order (head -> neck ->
+backbone), i.e. in the order backward produces gradients, so the first buckets fly while the backbone is still in
+backward.  ``torch.distributed`` is the transport (backend "nccl" is RCCL on ROCm; "gloo" for CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ['init_from_env', 'GradientReducer', 'broadcast_parameters', 'shard_targets']
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK (torchrun contract).
+    Returns (rank, world, local_rank).  A no-op (0, 1, 0) when WORLD_SIZE is absent or 1."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank ``src``'s parameters and buffers (DataParallel replicates from GPU 0)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def shard_targets(targets, rank, per_rank_batch):
+    """Rows of a global [T,6] target table that belong to this rank's images, re-based to local image indices."""
+    lo = rank * per_rank_batch
+    keep = (targets[:, 0] >= lo) & (targets[:, 0] < lo + per_rank_batch)
+    out = targets[keep].clone()
+    out[:, 0] -= lo
+    return out
+
+
+class GradientReducer:
+    """Bucketed, overlapped gradient averaging.
+
+        reducer = GradientReducer(model.parameters())
+        loss.backward()          # hooks copy each finished gradient into its bucket; full buckets start reducing
+        reducer.finish()         # wait for the collectives; p.grad are now views of the averaged buckets
+        optimizer.step()
+
+    Buckets are launched strictly in index order so that every rank issues the same sequence of collectives.
+    """
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True):
+        self.group, self.average = group, average
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        order = list(reversed(self.params))               # backward produces gradients roughly in reverse order
+        self.buckets, self.where = [], {}
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._close(cur)
+        self.pending = [0] * len(self.buckets)
+        self.handles = [None] * len(self.buckets)
+        self.next_launch = 0
+        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def _close(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            self.where[p] = (len(self.buckets), len(views) - 1)
+            off += p.numel()
+        self.buckets.append((flat, plist, views))
+
+    def reset(self):
+        self.pending = [len(b[1]) for b in self.buckets]
+        self.handles = [None] * len(self.buckets)
+        self.next_launch = 0
+
+    def _on_grad(self, p):
+        bi, vi = self.where[p]
+        view = self.buckets[bi][2][vi]
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view                                  # the optimizer reads the (soon averaged) bucket
+        self.pending[bi] -= 1
+        self._launch_ready()
+
+    def _launch_ready(self):
+        while self.next_launch < len(self.buckets) and self.pending[self.next_launch] <= 0:
+            self._launch(self.next_launch)
+            self.next_launch += 1
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        flat = self.buckets[bi][0]
+        backend = dist.get_backend(self.group)
+        if self.average and backend == 'nccl':
+            self.handles[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False)
+        else:
+            self.handles[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), self.average)
+
+    def finish(self):
+        """Launch what is still outstanding (parameters that received no gradient contribute zeros), wait for every
+        collective and re-arm for the next step."""
+        for bi in range(self.next_launch, len(self.buckets)):
+            flat, plist, views = self.buckets[bi]
+            for p, v in zip(plist, views):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    if p.grad is None:
+                        v.zero_()
+                    else:
+                        v.copy_(p.grad)
+                    p.grad = v
+            self._launch(bi)
+        self.next_launch = len(self.buckets)
+        for bi, h in enumerate(self.handles):
+            if h is not None:
+                h[0].wait()
+                if h[1]:
+                    self.buckets[bi][0].div_(self.world)
+        self.reset()
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()

@@ -1,0 +1,96 @@
+"""world_size-2 tests of the data-parallel path on CPU (gloo): the bucketed, hook-driven gradient reducer must
+produce exactly the average of the per-rank gradients, launch its collectives during backward in a rank-independent
+order, and the target sharding must re-base image indices."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from fastvision_amd import parallel
+    r, w, _ = parallel.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                      # ranks start different; broadcast makes them equal
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    parallel.broadcast_parameters(net)
+    reducer = parallel.GradientReducer(net.parameters(), bucket_bytes=600)         # forces several buckets
+    assert len(reducer.buckets) >= 3
+    results = []
+    for step in range(2):
+        g = torch.Generator().manual_seed(7 + rank + 10 * step)
+        x = torch.randn(5, 16, generator=g)
+        net.zero_grad()
+        net(x).square().sum().backward()
+        launched_during_backward = reducer.next_launch
+        reducer.finish()
+        results.append(([p.grad.clone() for p in net.parameters()], launched_during_backward))
+    out[rank] = (results, [p.detach().clone() for p in net.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    return out
+
+
+def test_reducer_averages_gradients_world2():
+    out = _run(2)
+    (res0, params0), (res1, params1) = out[0], out[1]
+    assert all(torch.equal(a, b) for a, b in zip(params0, params1))            # broadcast_parameters
+    for step in range(2):
+        g0, launched0 = res0[step]
+        g1, launched1 = res1[step]
+        assert launched0 == launched1 and launched0 >= 2                     # buckets went out during backward
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)                                           # identical after the all-reduce
+        # reference: average of the two ranks' local gradients, recomputed single-process
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+        with torch.no_grad():
+            for p, v in zip(net.parameters(), params0):
+                p.copy_(v)
+        acc = [torch.zeros_like(p) for p in net.parameters()]
+        for rank in range(2):
+            g = torch.Generator().manual_seed(7 + rank + 10 * step)
+            x = torch.randn(5, 16, generator=g)
+            net.zero_grad()
+            net(x).square().sum().backward()
+            for a, p in zip(acc, net.parameters()):
+                a += p.grad / 2
+        for a, b in zip(acc, g0):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_single_process_reducer_is_a_noop_average():
+    from fastvision_amd import parallel
+    net = torch.nn.Linear(4, 3)
+    red = parallel.GradientReducer(net.parameters())
+    net(torch.ones(2, 4)).sum().backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    red.finish()
+    assert all(torch.equal(a, p.grad) for a, p in zip(want, net.parameters()))
+    assert all(p.grad.data_ptr() == red.buckets[red.where[p][0]][2][red.where[p][1]].data_ptr() for p in net.parameters())
+    red.remove()
+
+
+def test_shard_targets_rebases_image_index():
+    from fastvision_amd import parallel
+    t = torch.tensor([[0, 1, .5, .5, .1, .1], [1, 2, .5, .5, .1, .1], [2, 3, .5, .5, .1, .1], [3, 4, .5, .5, .1, .1]])
+    s = parallel.shard_targets(t, rank=1, per_rank_batch=2)
+    assert s[:, 0].tolist() == [0.0, 1.0] and s[:, 1].tolist() == [3.0, 4.0]
+    assert parallel.shard_targets(t, 0, 2)[:, 1].tolist() == [1.0, 2.0]
