@@ -28,25 +28,43 @@ PEAK_F32_TFLOPS = 157.3
 TRAIN_GFLOP_PER_IMAGE_640 = 466.97   # fwd + dgrad (not conv0) + wgrad conv FLOPs
 
 
-def cpu_baseline(size, seconds=12.0):
-    """Time the CPU oracle on a bounded sample of the same workload (smaller batch, same image size)."""
+def usable_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(size, budget_s=25.0):
+    """Time the CPU oracle on a bounded sample of the same workload: one image of the same size per step."""
     from oracle import train as otrain
     from fastvision_amd.synthetic import synthetic_batch
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    batch = 2
+    batch = 1
     images, tg = synthetic_batch(batch, size)
     net, crit = otrain.make_library(20220504)
     opt = otrain.make_adam(net)
-    otrain.train_steps(net, crit, opt, images, tg, 1)                  # warm-up
+    print(f'[bench] cpu_baseline: oracle on {cores} threads, {batch}x3x{size}x{size} ...', file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    _, tw = otrain.train_steps(net, crit, opt, images, tg, 1)          # warm-up (also bounds the cost of a step)
     times = []
-    t_end = time.perf_counter() + seconds
-    while len(times) < 3 and (not times or time.perf_counter() < t_end):
+    while len(times) < 3 and time.perf_counter() - t0 + tw[0] < budget_s:
         _, t = otrain.train_steps(net, crit, opt, images, tg, 1)
         times.append(t[0])
+        print(f'[bench] cpu_baseline: step {len(times)} {t[0]:.2f} s', file=sys.stderr, flush=True)
+    warm_only = not times
+    if warm_only:
+        times = tw
     med = sorted(times)[len(times) // 2]
-    return {'value': batch / med, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'CPU oracle (port of the reference CPU path), fp32, 1 warm-up + {len(times)} timed steps of '
+    return {'value': round(batch / med, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'CPU oracle (port of the reference CPU path: same model, yolov3_loss, Adam, utils/fit.py step), fp32, '
+                      f'{"warm-up step only" if warm_only else f"1 warm-up + {len(times)} timed steps"} of '
                       f'{batch}x3x{size}x{size}, median {med:.2f} s/step, torch threads = {cores}'}
 
 
@@ -131,7 +149,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         summ = kt.summary()
