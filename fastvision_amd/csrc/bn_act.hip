@@ -18,27 +18,38 @@ __device__ __forceinline__ float silu_grad(float u) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward statistics -> coefficients.  Block = 16 channels x 16 partial-row groups.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* running_mean, float* running_var, int64_t* nbt,
-                                                          float momentum, float eps, float* save_mean, float* save_rstd,
-                                                          float* scale, float* shift) {
-    __shared__ double red[2][16][17];
+// forward statistics -> coefficients.  Block = 16 channels x 64 partial-row groups (1024 threads): the partial
+// table [nblocks][2][C] is summed with 4 independent loads in flight per thread, then in double across groups.
+constexpr int FIN_G = 64;
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c, int ry, double& s1,
+                                                double& s2) {
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int b = ry;
+    for (; b + FIN_G < nblocks; b += 2 * FIN_G) {
+        const float p0 = part[((int64_t)b * 2 + 0) * C + c], q0 = part[((int64_t)b * 2 + 1) * C + c];
+        const float p1 = part[((int64_t)(b + FIN_G) * 2 + 0) * C + c], q1 = part[((int64_t)(b + FIN_G) * 2 + 1) * C + c];
+        a0 += p0; b0 += q0; a1 += p1; b1 += q1;
+    }
+    if (b < nblocks) { a0 += part[((int64_t)b * 2 + 0) * C + c]; b0 += part[((int64_t)b * 2 + 1) * C + c]; }
+    s1 = (double)a0 + (double)a1;
+    s2 = (double)b0 + (double)b1;
+}
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* running_mean, float* running_var, int64_t* nbt,
+                                                           float momentum, float eps, float* save_mean, float* save_rstd,
+                                                           float* scale, float* shift) {
+    __shared__ double red[2][FIN_G][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = ry; b < nblocks; b += 16) {
-            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
-            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
-        }
+    if (c < C) reduce_partials(part, nblocks, C, c, ry, s1, s2);
     red[0][ry][cx] = s1;
     red[1][ry][cx] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
         s1 = s2 = 0.0;
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < FIN_G; ++k) {
             s1 += red[0][k][cx];
             s2 += red[1][k][cx];
         }
@@ -176,24 +187,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
-                                                              const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                                              float* dgamma, float* dbeta, int accumulate, float* coef) {
-    __shared__ double red[2][16][17];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                               float* dgamma, float* dbeta, int accumulate, float* coef) {
+    __shared__ double red[2][FIN_G][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = ry; b < nblocks; b += 16) {
-            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
-            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
-        }
+    if (c < C) reduce_partials(part, nblocks, C, c, ry, s1, s2);
     red[0][ry][cx] = s1;
     red[1][ry][cx] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
         s1 = s2 = 0.0;
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < FIN_G; ++k) {
             s1 += red[0][k][cx];
             s2 += red[1][k][cx];
         }
@@ -352,7 +359,7 @@ int fva_bn_finalize(const float* part, int32_t nblocks, int64_t count, int32_t C
                     float* save_mean, float* save_rstd, float* scale, float* shift, void* stream) {
     if (!part || !gamma || !beta || !save_mean || !save_rstd || !scale || !shift || nblocks <= 0 || count <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblocks, (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, part, nblocks, (double)count,
                        C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, save_mean, save_rstd,
                        scale, shift);
     FVA_LAUNCH_CHECK("bn_finalize_kernel");
@@ -434,7 +441,7 @@ int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
     if (!partial || !gamma || !save_rstd || !dgamma || !dbeta || !coef || nblocks <= 0 || M <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, (double)M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, partial, nblocks, (double)M, C,
                        gamma, save_rstd, dgamma, dbeta, accumulate, coef);
     FVA_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     return FVA_OK;

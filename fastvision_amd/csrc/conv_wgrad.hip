@@ -25,7 +25,7 @@ struct WgradParams {
     FastDiv div_ow, div_ohw;
     int x_img, x_row, sy, sx, x_y0, x_x0;
     int dy_img, dy_row, dy_pad, dy_pitch;
-    int64_t dy_zero_pix;
+    uint32_t dy_zero_off;  // byte offset of a pixel that is guaranteed zero (halo corner)
     int ntaps;
     int tap_pix[9];
     int ntn, ntc, ksplit, mchunk;
@@ -69,29 +69,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int chunk = (lane & 15) ^ f;
     const bool a_ok = n0 + chunk * EPC < p.N;  // columns beyond N / C feed only unused outputs: point them
     const bool b_ok = c0 + chunk * EPC < p.C;  // at column 0 to stay inside the buffers
-    const int a_col = a_ok ? n0 + chunk * EPC : 0;
-    const int b_col = b_ok ? c0 + chunk * EPC : 0;
+    const uint32_t a_colb = (uint32_t)(a_ok ? n0 + chunk * EPC : 0) * (uint32_t)sizeof(T);
+    const uint32_t b_colb = (uint32_t)(b_ok ? c0 + chunk * EPC : 0) * (uint32_t)sizeof(T);
+    const uint32_t dy_pixb = (uint32_t)p.dy_pitch * (uint32_t)sizeof(T), x_pixb = (uint32_t)p.C * (uint32_t)sizeof(T);
 
+    // Address generation: each lane decodes ONE pixel row per k-step (the row owned by lane & 15) and the four
+    // rows a lane needs for its DMA instructions are fetched from their owner lanes by wave shuffles.
+    const int own_row = ((((lane & 15) >> 2) * 4 + w) * 4) + (lane & 3);
+    const char* dy_base = (const char*)p.dy;
+    const char* x_base = (const char*)p.x + (int64_t)tpix * x_pixb;
     auto load_step = [&](int step, int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + OP_BYTES;
+        int m = mbeg + step * BKP + own_row;
+        const bool live = m < mend;
+        m = m < p.M ? m : p.M - 1;
+        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+        const uint32_t oy = fd_div(rem, p.div_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        const uint32_t dpix = b * (uint32_t)p.dy_img + (oy + p.dy_pad) * (uint32_t)p.dy_row + (ox + p.dy_pad);
+        const uint32_t xpix = b * (uint32_t)p.x_img + (oy * p.sy + p.x_y0) * (uint32_t)p.x_row + (ox * p.sx + p.x_x0);
+        const uint32_t own_dy = live ? dpix * dy_pixb : p.dy_zero_off;
+        const uint32_t own_x = xpix * x_pixb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int R = (i * 4 + w) * 4 + lrow;
-            int m = mbeg + step * BKP + R;
-            const bool live = m < mend;
-            m = m < p.M ? m : p.M - 1;
-            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
-            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
-            const uint32_t oy = fd_div(rem, p.div_ow);
-            const uint32_t ox = rem - oy * (uint32_t)p.OW;
-            const int64_t dpix = live ? (int64_t)b * p.dy_img + (int64_t)(oy + p.dy_pad) * p.dy_row + (ox + p.dy_pad)
-                                      : p.dy_zero_pix;
-            const int64_t xpix = (int64_t)b * p.x_img + (int64_t)(oy * p.sy + p.x_y0) * p.x_row + (ox * p.sx + p.x_x0) + tpix;
-            const T* ga = (const T*)p.dy + dpix * p.dy_pitch + a_col;
-            const T* gb = (const T*)p.x + xpix * p.C + b_col;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ga), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(gb), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
+            const uint32_t doff = (uint32_t)__shfl((int)own_dy, i * 4 + lrow) + a_colb;
+            const uint32_t xoff = (uint32_t)__shfl((int)own_x, i * 4 + lrow) + b_colb;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + doff), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + xoff), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
         }
     };
 
@@ -110,16 +116,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     load_step(0, 0);
     for (int st = 0; st < steps; ++st) {
         __syncthreads();
-        if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
         const char* sA = smem + (st & 1) * STAGE;
         const char* sB = sA + OP_BYTES;
         if constexpr (IS_BF16) {
             // transposed read: lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a
-            // 4-row x 16-column block and receives column (lane&15) of the 4 rows
+            // 4-row x 16-column block and receives column (lane&15) of the 4 rows.  All fragments of the tile are
+            // read BEFORE the next tile's DMA is issued: hipcc waits vmcnt(0) in front of a ds_read_tr that
+            // follows an LDS-DMA, which would serialise the DMA with the MFMAs.
             const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+            bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[4], bfr[4];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int row = kk * 32 + 8 * g + 4 * hh + q;
@@ -136,18 +143,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                         const bf16x4 ba = __builtin_bit_cast(bf16x4, va), bb = __builtin_bit_cast(bf16x4, vb);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            af[t][hh * 4 + e] = ba[e];
-                            bfr[t][hh * 4 + e] = bb[e];
+                            af[kk][t][hh * 4 + e] = ba[e];
+                            bfr[kk][t][hh * 4 + e] = bb[e];
                         }
                     }
                 }
+            if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        acc16[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[ct], acc16[nt][ct], 0, 0, 0);
-            }
+                        acc16[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][nt], bfr[kk][ct], acc16[nt][ct], 0, 0, 0);
         } else {
+            if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
             const int r = lane & 31, h = lane >> 5;
             const float* fa = (const float*)sA + wr * 32 + r;
             const float* fb = (const float*)sB + wc * 32 + r;
@@ -183,17 +193,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// dw[n][c][t] (+)= sum_ks slab[ks][t][n][c]; one thread per (n, c) writes its k*k taps contiguously
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N, int C, int ntaps,
-                                    int ksplit, int accumulate) {
+// dw[n][c][t] (+)= sum_ks slab[ks][t][n][c].  Block = 64 consecutive (n,c) pairs x 4 split-K groups: every load is
+// a coalesced 256-B row of the slab, partial sums are combined in a fixed order (deterministic), and the k*k taps
+// of the 64 pairs leave as one contiguous run of the OIHW gradient.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N, int C,
+                                                           int ntaps, int ksplit, int accumulate) {
+    __shared__ float part[4][9][64];
+    __shared__ float outs[64 * 9];
     const int64_t nc = (int64_t)N * C;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nc; i += (int64_t)gridDim.x * blockDim.x) {
-        for (int t = 0; t < ntaps; ++t) {
-            float s = 0.f;
-            for (int k = 0; k < ksplit; ++k) s += slab[((int64_t)k * ntaps + t) * nc + i];
-            float* o = dw + i * ntaps + t;
-            *o = accumulate ? *o + s : s;
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int li = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = i0 + li;
+    for (int t = 0; t < ntaps; ++t) {
+        float s = 0.f;
+        if (i < nc) {
+            const float* src = slab + (int64_t)t * nc + i;
+            int k = grp;
+            for (; k + 12 < ksplit; k += 16) {
+                const float v0 = src[(int64_t)k * ntaps * nc], v1 = src[(int64_t)(k + 4) * ntaps * nc];
+                const float v2 = src[(int64_t)(k + 8) * ntaps * nc], v3 = src[(int64_t)(k + 12) * ntaps * nc];
+                s += (v0 + v1) + (v2 + v3);
+            }
+            for (; k < ksplit; k += 4) s += src[(int64_t)k * ntaps * nc];
         }
+        part[grp][t][li] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * ntaps; e += 256) {
+        const int t = e / 64, l = e - t * 64;
+        outs[l * ntaps + t] = (part[0][t][l] + part[1][t][l]) + (part[2][t][l] + part[3][t][l]);
+    }
+    __syncthreads();
+    const int64_t valid = (nc - i0 < 64 ? nc - i0 : 64) * ntaps;
+    for (int e = threadIdx.x; e < valid; e += 256) {
+        float* o = dw + i0 * ntaps + e;
+        *o = accumulate ? *o + outs[e] : outs[e];
     }
 }
 
@@ -210,7 +244,7 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     pl.ntc = cdiv(d->Cin, pl.tile);
     pl.ntaps = d->ksize * d->ksize;
     const int tiles = pl.ntn * pl.ntc * pl.ntaps;
-    int ks = cdiv(1024, tiles);
+    int ks = cdiv(512, tiles);   // ~2 resident blocks per CU; fewer partial tiles to write and reduce
     const int max_by_m = cdiv(pl.M, 256);
     if (ks > max_by_m) ks = max_by_m;
     const int64_t per = (int64_t)pl.ntaps * d->Cout * d->Cin * 4;
@@ -243,6 +277,10 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     if (d->Cin % epc || d->Cout % epc) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: channels must be multiples of %d", epc);
     if (d->in_pad < d->ksize / 2) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: in_pad too small");
     if (d->dy_pad < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: dy buffer needs a zero border (dy_pad >= 1)");
+    const int64_t esz = d->dtype == FVA_BF16 ? 2 : 4;
+    if ((int64_t)d->B * (d->H + 2 * d->in_pad) * (d->W + 2 * d->in_pad) * d->Cin * esz >= (1ll << 32) ||
+        (int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cout * esz >= (1ll << 32))
+        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
     plan_wgrad(d, pl);
     const int64_t need = (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
@@ -266,7 +304,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     p.dy_img = (pl.OH + 2 * d->dy_pad) * p.dy_row;
     p.dy_pad = d->dy_pad;
     p.dy_pitch = d->Cout;
-    p.dy_zero_pix = 0;  // top-left border pixel of image 0 is always zero
+    p.dy_zero_off = 0;  // top-left border pixel of image 0 is always zero
     p.ntaps = pl.ntaps;
     for (int kh = 0; kh < d->ksize; ++kh)
         for (int kw = 0; kw < d->ksize; ++kw) p.tap_pix[kh * d->ksize + kw] = kh * p.x_row + kw;
@@ -283,9 +321,8 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), smem, s, p);
     FVA_LAUNCH_CHECK("wgrad_kernel");
     const int64_t nc = (int64_t)d->Cout * d->Cin;
-    const int rgrid = (int)((nc + 255) / 256 < 2048 ? (nc + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, d->Cout, d->Cin,
-                       pl.ntaps, pl.ksplit, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((nc + 63) / 64)), dim3(256), 0, s, (const float*)workspace, dw, d->Cout,
+                       d->Cin, pl.ntaps, pl.ksplit, accumulate);
     FVA_LAUNCH_CHECK("wgrad_reduce_kernel");
     return FVA_OK;
 }
