@@ -55,7 +55,7 @@ class _ConvBlock(nn.Module):
 
     def forward(self, x):
         conv = self.conv
-        if conv.in_channels <= 4 and conv.out_channels == 32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1):
+        if conv.in_channels <= 3 and conv.out_channels == 32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1):
             return ops.stem(x, conv, self.bn)          # network input: fp32 NCHW images, no input gradient
         return ops.conv_bn_silu(x, conv, self.bn)
 

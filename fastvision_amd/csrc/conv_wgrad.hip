@@ -29,6 +29,7 @@ struct WgradParams {
     int ntaps;
     int tap_pix[9];
     int ntn, ntc, ksplit, mchunk;
+    int tpt, ngroups;  // taps packed side by side in one column tile (thin layers: C < tile), tap groups
 };
 
 template <typename T>
@@ -46,38 +47,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int per_ks = p.ntaps * p.ntn * p.ntc;
+    const int per_ks = p.ngroups * p.ntn * p.ntc;
     const int ks = logical / per_ks;
     logical -= ks * per_ks;
-    const int tap = logical / (p.ntn * p.ntc);
-    logical -= tap * (p.ntn * p.ntc);
+    const int tg = logical / (p.ntn * p.ntc);  // tap group (a single tap when tpt == 1)
+    logical -= tg * (p.ntn * p.ntc);
     const int tn = logical / p.ntc, tc = logical - tn * p.ntc;
     const int n0 = tn * TILE, c0 = tc * TILE;
     const int mbeg = ks * p.mchunk;
     const int mend = (mbeg + p.mchunk < p.M) ? mbeg + p.mchunk : p.M;
     const int steps = p.mchunk / BKP;
 
-    // tap pixel offset without dynamic kernarg indexing
-    int tpix = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-        if (i == tap) tpix = p.tap_pix[i];
-
     // ---- LDS-DMA source mapping: one instruction = 4 pixel rows x 256 B; lane -> (row, 16-B chunk) ---------
     const int lrow = lane >> 4;
     const int f = IS_BF16 ? ((lrow << 2) | w) : 0;  // swizzle of this lane's rows: ((R&3)<<2)|((R>>2)&3)
     const int chunk = (lane & 15) ^ f;
-    const bool a_ok = n0 + chunk * EPC < p.N;  // columns beyond N / C feed only unused outputs: point them
-    const bool b_ok = c0 + chunk * EPC < p.C;  // at column 0 to stay inside the buffers
-    const uint32_t a_colb = (uint32_t)(a_ok ? n0 + chunk * EPC : 0) * (uint32_t)sizeof(T);
-    const uint32_t b_colb = (uint32_t)(b_ok ? c0 + chunk * EPC : 0) * (uint32_t)sizeof(T);
     const uint32_t dy_pixb = (uint32_t)p.dy_pitch * (uint32_t)sizeof(T), x_pixb = (uint32_t)p.C * (uint32_t)sizeof(T);
+    const bool a_ok = n0 + chunk * EPC < p.N;  // columns beyond N / C feed only unused outputs: point them
+    const uint32_t a_colb = (uint32_t)(a_ok ? n0 + chunk * EPC : 0) * (uint32_t)sizeof(T);  // at column 0 (in bounds)
+    // B column -> (tap, channel): with tpt > 1 the tile holds tpt taps of all C channels side by side
+    const int jcol = c0 + chunk * EPC;
+    const int tsub = p.tpt > 1 ? jcol / p.C : 0;
+    const int ccol = p.tpt > 1 ? jcol - tsub * p.C : jcol;
+    const int my_tap = tg * p.tpt + tsub;
+    const bool b_ok = my_tap < p.ntaps && ccol < p.C;
+    int tpix = 0;  // tap pixel offset without dynamic kernarg indexing
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (i == (b_ok ? my_tap : tg * p.tpt)) tpix = p.tap_pix[i];
+    const uint32_t b_colb = (uint32_t)tpix * x_pixb + (uint32_t)(b_ok ? ccol : 0) * (uint32_t)sizeof(T);
 
     // Address generation: each lane decodes ONE pixel row per k-step (the row owned by lane & 15) and the four
     // rows a lane needs for its DMA instructions are fetched from their owner lanes by wave shuffles.
     const int own_row = ((((lane & 15) >> 2) * 4 + w) * 4) + (lane & 3);
     const char* dy_base = (const char*)p.dy;
-    const char* x_base = (const char*)p.x + (int64_t)tpix * x_pixb;
+    const char* x_base = (const char*)p.x;
     auto load_step = [&](int step, int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + OP_BYTES;
@@ -171,7 +175,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 
     // ---- partial tile -> slab[ks][tap][N][C] ------------------------------------------------------------
-    float* out = p.slab + ((int64_t)ks * p.ntaps + tap) * p.N * p.C;
+    float* out = p.slab + (int64_t)ks * p.ntaps * p.N * p.C;
+    auto store = [&](int n, int j, float v) {  // j = column inside the tile
+        int tap, c;
+        if (p.tpt > 1) {
+            const int ts = j / p.C;
+            tap = tg * p.tpt + ts;
+            c = j - ts * p.C;
+        } else {
+            tap = tg;
+            c = c0 + j;
+        }
+        if (n < p.N && c < p.C && tap < p.ntaps) out[((int64_t)tap * p.N + n) * p.C + c] = v;
+    };
     if constexpr (IS_BF16) {
         const int r = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -179,17 +195,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wr * 64 + nt * 16 + g * 4 + j, c = c0 + wc * 64 + ct * 16 + r;
-                    if (n < p.N && c < p.C) out[(int64_t)n * p.C + c] = acc16[nt][ct][j];
-                }
+                for (int j = 0; j < 4; ++j) store(n0 + wr * 64 + nt * 16 + g * 4 + j, wc * 64 + ct * 16 + r, acc16[nt][ct][j]);
     } else {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = n0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, c = c0 + wc * 32 + r;
-            if (n < p.N && c < p.C) out[(int64_t)n * p.C + c] = acc32[e];
-        }
+        for (int e = 0; e < 16; ++e) store(n0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wc * 32 + r, acc32[e]);
     }
 }
 
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan {
-    int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW;
+    int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW, tpt, ngroups;
 };
 
 int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
@@ -243,7 +253,9 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     pl.ntn = cdiv(d->Cout, pl.tile);
     pl.ntc = cdiv(d->Cin, pl.tile);
     pl.ntaps = d->ksize * d->ksize;
-    const int tiles = pl.ntn * pl.ntc * pl.ntaps;
+    pl.tpt = (d->Cin < pl.tile && pl.tile % d->Cin == 0 && pl.ntaps > 1) ? pl.tile / d->Cin : 1;
+    pl.ngroups = cdiv(pl.ntaps, pl.tpt);
+    const int tiles = pl.ntn * pl.ntc * pl.ngroups;
     int ks = cdiv(512, tiles);   // ~2 resident blocks per CU; fewer partial tiles to write and reduce
     const int max_by_m = cdiv(pl.M, 256);
     if (ks > max_by_m) ks = max_by_m;
@@ -312,7 +324,9 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     p.ntc = pl.ntc;
     p.ksplit = pl.ksplit;
     p.mchunk = pl.mchunk;
-    const int grid = pl.ksplit * pl.ntaps * pl.ntn * pl.ntc;
+    p.tpt = pl.tpt;
+    p.ngroups = pl.ngroups;
+    const int grid = pl.ksplit * pl.ngroups * pl.ntn * pl.ntc;
     const int smem = 2 * 2 * 64 * 256;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == FVA_BF16)

@@ -1,4 +1,4 @@
-// Stem convolution (3x3, stride 1, pad 1, Cin <= 4, Cout == 32) read straight from the caller's fp32 NCHW
+// Stem convolution (3x3, stride 1, pad 1, Cin <= 3, Cout == 32) read straight from the caller's fp32 NCHW
 // images: 27-deep dot products are too shallow for MFMA, so this is a direct VALU kernel, one output pixel
 // (all 32 channels) per lane.  HBM-bound: reads 12 B and writes 64 B (bf16) per pixel.
 //
@@ -84,21 +84,29 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
-// dW partial per block over a strided set of 128-pixel tiles: slab[blk][co][j].  Lanes 0-127 stage the dY rows,
-// lanes 128-255 the 3x3 input patches; then lane (co, jg) accumulates outputs j = jg, jg+8, ...
+// dW partial per block over a strided set of 128-pixel tiles: slab[blk][co][j].  Per tile, lanes 0-127 stage the dY
+// rows and lanes 128-255 the 3x3 input patches in LDS (fp32); then each of 4 pixel groups x 56 lanes accumulates a
+// 4 (co) x 4 (j) register block over its 32 pixels with two 16-byte LDS reads per 16 FMAs.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy,
                                                          float* __restrict__ slab, int B, int Cin, int H, int W, int64_t M,
                                                          int ntiles) {
-    __shared__ float sdy[128 * 33];
-    __shared__ float spt[128 * 37];
+    constexpr int DS = 36, PS = 40;  // LDS row strides in floats (16-byte aligned, padded against bank conflicts)
+    __shared__ __attribute__((aligned(16))) float sdy[128 * DS];
+    __shared__ __attribute__((aligned(16))) float spt[128 * PS];
     const int tid = threadIdx.x;
     const int J = Cin * 9;
-    const int co = tid & 31, jg = tid >> 5;
+    const int grp = tid >> 6, t = tid & 63;
+    const int co4 = t & 7, j4 = t >> 3;       // 8 x 9 register blocks cover 32 co x 36 j; lanes with j4*4 >= J idle
+    const bool worker = j4 * 4 < J;
     const int px = tid & 127, role = tid >> 7;
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // j = jg + 8*i, i < 5 (J <= 36)
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t m = (int64_t)t * 128 + px;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int64_t m = (int64_t)tl * 128 + px;
         const bool live = m < M;
         constexpr int EPC = Vec16<T>::N;
         if (role == 0) {
@@ -107,37 +115,52 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 Vec16<T> v;
                 if (live) v = *(const Vec16<T>*)(dy + m * CO + q * EPC);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) sdy[px * 33 + q * EPC + e] = live ? v.get(e) : 0.f;
+                for (int e = 0; e < EPC; ++e) sdy[px * DS + q * EPC + e] = live ? v.get(e) : 0.f;
             }
         } else {
             const int x = (int)(m % W), yy = (int)((m / W) % H), b = (int)(m / ((int64_t)W * H));
-            for (int ci = 0; ci < Cin; ++ci) {
+            for (int ci = 0; ci < 4; ++ci) {
                 const float* plane = img + ((int64_t)b * Cin + ci) * H * W;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
                         const int iy = yy + kh - 1, ix = x + kw - 1;
-                        spt[px * 37 + ci * 9 + kh * 3 + kw] =
-                            (live && iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(int64_t)iy * W + ix] : 0.f;
+                        spt[px * PS + ci * 9 + kh * 3 + kw] =
+                            (live && ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(int64_t)iy * W + ix] : 0.f;
                     }
             }
         }
         __syncthreads();
-        for (int p = 0; p < 128; ++p) {
-            const float g = sdy[p * 33 + co];
+        if (worker) {
+            const float* pd = sdy + grp * 32 * DS + co4 * 4;
+            const float* pp = spt + grp * 32 * PS + j4 * 4;
+#pragma unroll 4
+            for (int p = 0; p < 32; ++p) {
+                const float4 g = *(const float4*)(pd + p * DS);
+                const float4 v = *(const float4*)(pp + p * PS);
+                const float gv[4] = {g.x, g.y, g.z, g.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int j = jg + 8 * i;
-                if (j < J) acc[i] += g * spt[p * 37 + j];
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] += gv[a] * vv[c];
             }
         }
         __syncthreads();
     }
+    // combine the 4 pixel groups in fixed order, then one partial per block
+    float* red = sdy;  // 4 x 32 x 36 floats = 18 KiB (fits the dY staging area)
+    if (worker) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int j = jg + 8 * i;
-        if (j < J) slab[((int64_t)blockIdx.x * CO + co) * J + j] = acc[i];
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[(grp * CO + co4 * 4 + a) * 36 + j4 * 4 + c] = acc[a][c];
+    }
+    __syncthreads();
+    for (int e = tid; e < CO * J; e += 256) {
+        const int co = e / J, j = e - co * J;
+        const float v = (red[(0 * CO + co) * 36 + j] + red[(1 * CO + co) * 36 + j]) + (red[(2 * CO + co) * 36 + j] + red[(3 * CO + co) * 36 + j]);
+        slab[(int64_t)blockIdx.x * CO * J + e] = v;
     }
 }
 
@@ -160,7 +183,7 @@ int32_t fva_stem_stat_blocks(int B, int H, int W) { return cdiv((int64_t)B * H *
 int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* stats, int B, int Cin, int H, int W, int Cout,
                  void* stream) {
     if (!img || !w || !y) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: null pointer");
-    if (Cout != CO || Cin < 1 || Cin > 4) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: needs Cout==32, Cin<=4 (got %d, %d)", Cout, Cin);
+    if (Cout != CO || Cin < 1 || Cin > 3) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: needs Cout==32, Cin<=3 (got %d, %d)", Cout, Cin);
     const int64_t M = (int64_t)B * H * W;
     const int grid = cdiv(M, 256);
     hipStream_t s = (hipStream_t)stream;
@@ -182,7 +205,7 @@ int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout) {
 int fva_stem_wgrad(int dtype, const float* img, const void* dy, float* dw, int accumulate, void* workspace, int64_t workspace_bytes,
                    int B, int Cin, int H, int W, int Cout, void* stream) {
     if (!img || !dy || !dw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: null pointer");
-    if (Cout != CO || Cin < 1 || Cin > 4) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: needs Cout==32, Cin<=4");
+    if (Cout != CO || Cin < 1 || Cin > 3) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: needs Cout==32, Cin<=3");
     if (workspace_bytes < fva_stem_wgrad_workspace(B, Cin, H, W, Cout)) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_wgrad: workspace too small");
     const int64_t M = (int64_t)B * H * W;
     const int ntiles = cdiv(M, 128);

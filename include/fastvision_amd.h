@@ -79,7 +79,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d);
 
-/* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 4 (darknet53.py:73 `conv0`), direct kernel.
+/* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 3, Cout == 32 (darknet53.py:73 `conv0`), direct kernel.
  * y dense [B*H*W][Cout] dtype + BN partial stats;  wgrad from dy dense [B*H*W][Cout] (pad 0). */
 int fva_stem_fwd(int dtype, const float* images_nchw, const float* w_oihw, void* y, float* stats_partial,
                  int B, int Cin, int H, int W, int Cout, void* stream);
