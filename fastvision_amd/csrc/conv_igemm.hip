@@ -71,12 +71,15 @@ __device__ __forceinline__ void foreach_acc(Acc<float>& acc, int lane, F&& f) {
 }
 
 template <typename T, int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const IgemmParams p) {
     constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;               // 128-byte rows
     constexpr int WN = BN / 64;               // waves along n
+    constexpr int NW = (BM / 64) * WN;        // waves per block (4 or 8); each owns a 64x64 sub-tile
+    constexpr int NT = NW * 64;
+    static_assert(NW % 2 == 0, "the source swizzle assumes an even wave count");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_ITERS = BM / 32, B_ITERS = BN / 32;
+    constexpr int A_ITERS = BM / (8 * NW), B_ITERS = BN / (8 * NW);
     constexpr bool IS_BF16 = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int sub = p.halfrow ? (chunk & 3) : chunk;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-        int m = m0 + (i * 4 + w) * 8 + lrow;
+        int m = m0 + (i * NW + w) * 8 + lrow;
         m = m < p.M ? m : p.M - 1;
         const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
         const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-        int n = n0 + (i * 4 + w) * 8 + lrow;
+        int n = n0 + (i * NW + w) * 8 + lrow;
         n = n < p.N ? n : p.N - 1;
         b_ptr[i] = (const T*)p.wt + (int64_t)n * p.C + sub * EPC;
     }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     int* ktab = (int*)(smem + 2 * STAGE);
     {
         const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
-        for (int e = tid; e < nent; e += 256) {
+        for (int e = tid; e < nent; e += NT) {
             int t, kk;
             if (p.halfrow) { t = e; kk = 0; }
             else { t = e / p.kt_per_tap; kk = e - t * p.kt_per_tap; }
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int aoff = ktab[2 * e], boff = ktab[2 * e + 1];
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(sA + (i * NW + w) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(sB + (i * NW + w) * 1024), 16, 0, 0);
     };
 
     Acc<T> acc;
@@ -301,11 +304,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         });
         __syncthreads();
         constexpr int CPR = BN / 8;  // 16-B chunks per row
-        constexpr int ITERS = BM * CPR / 256;
+        constexpr int ITERS = BM * CPR / NT;
         bf16_t* out = (bf16_t*)p.out;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = it * 256 + tid;
+            const int c = it * NT + tid;
             const int row = c / CPR, cc = c - row * CPR;
             const int m = m0 + row, n = n0 + cc * 8;
             if (m < p.M && n < p.N) {
@@ -333,17 +336,24 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI>), dim3(mblocks * q.nblocks), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
     FVA_LAUNCH_CHECK("igemm_kernel");
     return FVA_OK;
 }
 
 inline bool wide_tile(int N) { return N >= 128; }
+// row-block height: 256x128 (8 waves, 85 flop per staged byte instead of 64) when it still yields >= 1.5 blocks per CU
+inline int tile_bm(int dtype, int M, int N) {
+    if (!wide_tile(N)) return 256;
+    if (dtype == FVA_BF16 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 384) return 256;
+    return 128;
+}
 
 template <int EPI>
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
     if (dtype == FVA_BF16) {
-        return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI>(p, s) : launch_one<bf16_t, 256, 64, EPI>(p, s);
+        if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI>(p, s);
+        return tile_bm(dtype, p.M, p.N) == 256 ? launch_one<bf16_t, 256, 128, EPI>(p, s) : launch_one<bf16_t, 128, 128, EPI>(p, s);
     }
     return wide_tile(p.N) ? launch_one<float, 128, 128, EPI>(p, s) : launch_one<float, 256, 64, EPI>(p, s);
 }
@@ -439,7 +449,7 @@ int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
     if (!d) return 0;
     const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
     const int64_t M = (int64_t)d->B * OH * OW;
-    return cdiv(M, wide_tile(d->Cout) ? 128 : 256);
+    return cdiv(M, tile_bm(d->dtype, (int)M, d->Cout));
 }
 
 static int setup_fwd(const fva_conv_desc* d, IgemmParams& p, const char* who) {
