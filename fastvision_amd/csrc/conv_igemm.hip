@@ -10,6 +10,8 @@
 //
 // Replaces nn.Conv2d forward/backward-data as issued by ConvBlock3x3/ConvBlock1x1
 // (reference classfication/models/darknet53.py:5-9, 22-44) and the head conv (detection/head/yolov3head.py:50).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -70,7 +72,12 @@ __device__ __forceinline__ void foreach_acc(Acc<float>& acc, int lane, F&& f) {
             for (int e = 0; e < 16; ++e) f(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, nt * 32 + r, nt, acc.a[mt][nt][e]);
 }
 
-template <typename T, int BM, int BN, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int EPI, int NSTAGE>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const IgemmParams p) {
     constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;               // 128-byte rows
@@ -121,7 +128,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 
     // per-k-tile element offsets (A: tap pixel offset * C + channel slice; B: tap matrix + channel slice),
     // tabulated once in LDS so the k loop does no division and no dynamic kernarg indexing
-    int* ktab = (int*)(smem + 2 * STAGE);
+    int* ktab = (int*)(smem + NSTAGE * STAGE);
     {
         const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
         for (int e = tid; e < nent; e += NT) {
@@ -165,13 +172,25 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 for (int e = 0; e < 16; ++e) acc.a[i][j][e] = 0.f;
     }
 
-    // ---- main loop: one barrier per k-tile; tile kt+1 is in flight while tile kt is multiplied -----------
-    load_tile(0, 0);
+    // ---- main loop: NSTAGE-deep LDS ring, one raw barrier per k-tile.  Tiles kt+1 .. kt+NSTAGE-2 stay in flight
+    // across the barrier (counted vmcnt: LDS-DMA retires in issue order), tile kt+NSTAGE-1 is issued right after
+    // it into the stage every wave has just finished reading.
+    constexpr int LPT = A_ITERS + B_ITERS;  // DMA instructions per wave and tile
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i)
+        if (i < p.ktiles) load_tile(i, i);
+    int st_cur = 0, st_next = NSTAGE - 1;
     for (int kt = 0; kt < p.ktiles; ++kt) {
-        __syncthreads();  // own DMA landed (vmcnt(0)) + everyone done with the other stage
-        if (kt + 1 < p.ktiles) load_tile(kt + 1, (kt + 1) & 1);
-        const char* sA = smem + (kt & 1) * STAGE;
+        const int ahead = p.ktiles - 1 - kt;  // tiles issued after kt that may stay in flight
+        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < p.ktiles) load_tile(kt + NSTAGE - 1, st_next);
+        const char* sA = smem + st_cur * STAGE;
         const char* sB = sA + A_BYTES;
+        st_next = st_cur;
+        st_cur = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
         if constexpr (IS_BF16) {
             const int r = lane & 15, g = lane >> 4, sr = (r >> 1) & 7;
             const char* pa = sA + (wr * 64 + r) * 128;
@@ -325,37 +344,56 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     }
 }
 
-template <typename T, int BM, int BN, int EPI>
+template <typename T, int BM, int BN, int EPI, int NSTAGE>
 int launch_one(const IgemmParams& p, hipStream_t s) {
     const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
     q.nblocks = cdiv(p.N, BN);
-    const int smem = 2 * (BM + BN) * 128 + 4096;  // stages + k-tile offset table
+    const int smem = NSTAGE * (BM + BN) * 128 + 4096;  // stages + k-tile offset table
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
     FVA_LAUNCH_CHECK("igemm_kernel");
     return FVA_OK;
 }
 
 inline bool wide_tile(int N) { return N >= 128; }
-// row-block height: 256x128 (8 waves, 85 flop per staged byte instead of 64) when it still yields >= 1.5 blocks per CU
+
+// Tile configuration of the wide (N >= 128) bf16 kernels: BM x 128 x NSTAGE.  FVA_IGEMM_TILE = "128x2" | "128x3" |
+// "128x4" | "256x2" | "256x3" overrides the default (tuning aid; the default is what the benchmarks run).
+struct WideCfg { int bm, stages; };
+inline WideCfg wide_cfg() {
+    static WideCfg cfg = [] {
+        WideCfg c{128, 2};
+        if (const char* e = getenv("FVA_IGEMM_TILE")) {
+            int bm = 0, st = 0;
+            if (sscanf(e, "%dx%d", &bm, &st) == 2 && (bm == 128 || bm == 256) && st >= 2 && st <= (bm == 128 ? 4 : 3)) c = WideCfg{bm, st};
+        }
+        return c;
+    }();
+    return cfg;
+}
 inline int tile_bm(int dtype, int M, int N) {
     if (!wide_tile(N)) return 256;
-    if (dtype == FVA_BF16 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 384) return 256;
+    if (dtype == FVA_BF16 && wide_cfg().bm == 256 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 384) return 256;
     return 128;
 }
 
 template <int EPI>
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
     if (dtype == FVA_BF16) {
-        if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI>(p, s);
-        return tile_bm(dtype, p.M, p.N) == 256 ? launch_one<bf16_t, 256, 128, EPI>(p, s) : launch_one<bf16_t, 128, 128, EPI>(p, s);
+        if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI, 2>(p, s);
+        const int st = wide_cfg().stages;
+        if (tile_bm(dtype, p.M, p.N) == 256)
+            return st == 3 ? launch_one<bf16_t, 256, 128, EPI, 3>(p, s) : launch_one<bf16_t, 256, 128, EPI, 2>(p, s);
+        if (st == 4 && wide_cfg().bm == 128) return launch_one<bf16_t, 128, 128, EPI, 4>(p, s);
+        if (st == 3 && wide_cfg().bm == 128) return launch_one<bf16_t, 128, 128, EPI, 3>(p, s);
+        return launch_one<bf16_t, 128, 128, EPI, 2>(p, s);
     }
-    return wide_tile(p.N) ? launch_one<float, 128, 128, EPI>(p, s) : launch_one<float, 256, 64, EPI>(p, s);
+    return wide_tile(p.N) ? launch_one<float, 128, 128, EPI, 2>(p, s) : launch_one<float, 256, 64, EPI, 2>(p, s);
 }
 
 int check_desc(const fva_conv_desc* d, const char* who) {
