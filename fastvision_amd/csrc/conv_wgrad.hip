@@ -33,7 +33,7 @@ struct WgradParams {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     constexpr bool IS_BF16 = sizeof(T) == 2;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int TILE = 16 * EPC;  // channels per tile side: 128 bf16 / 64 f32 (256-byte rows)
@@ -128,9 +128,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             // read BEFORE the next tile's DMA is issued: hipcc waits vmcnt(0) in front of a ds_read_tr that
             // follows an LDS-DMA, which would serialise the DMA with the MFMAs.
             const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+            using s16x8 = __attribute__((ext_vector_type(8))) short;
             bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                s16x4 la[2][4], lb[2][4];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int row = kk * 32 + 8 * g + 4 * hh + q;
@@ -140,18 +142,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                     for (int t = 0; t < 4; ++t) {
                         const int cha = wr * 8 + t * 2 + (pp >> 1);
                         const int chb = wc * 8 + t * 2 + (pp >> 1);
-                        const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        la[hh][t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sA + rbase + ((cha ^ fr) << 4)));
-                        const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        lb[hh][t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sB + rbase + ((chb ^ fr) << 4)));
-                        const bf16x4 ba = __builtin_bit_cast(bf16x4, va), bb = __builtin_bit_cast(bf16x4, vb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            af[kk][t][hh * 4 + e] = ba[e];
-                            bfr[kk][t][hh * 4 + e] = bb[e];
-                        }
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // k = 8g + (0..3 | 4..7): concatenate the two transposed reads
+                    af[kk][t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(la[0][t], la[1][t], 0, 1, 2, 3, 4, 5, 6, 7));
+                    bfr[kk][t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lb[0][t], lb[1][t], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
             if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)

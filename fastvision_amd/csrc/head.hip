@@ -37,14 +37,23 @@ __global__ __launch_bounds__(256) void head_bias_partial_kernel(const float* __r
     }
 }
 
-__global__ void head_bias_final_kernel(const float* __restrict__ partial, const float* __restrict__ gscale, float* __restrict__ dbias,
-                                       int N, int nblocks, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// one block per output channel: 256 lanes share the partial rows, fixed-order tree in LDS (deterministic)
+__global__ __launch_bounds__(256) void head_bias_final_kernel(const float* __restrict__ partial, const float* __restrict__ gscale,
+                                                              float* __restrict__ dbias, int N, int nblocks, int accumulate) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * N + n];
-    const float v = (float)s * (gscale ? *gscale : 1.f);
-    dbias[n] = accumulate ? dbias[n] + v : v;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partial[(int64_t)b * N + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)red[0] * (gscale ? *gscale : 1.f);
+        dbias[n] = accumulate ? dbias[n] + v : v;
+    }
 }
 
 }  // namespace
@@ -71,7 +80,7 @@ extern "C" int fva_head_bwd_prepare(int dtype, const float* dhead, const float* 
     nblocks = (int)((M + rows - 1) / rows);
     hipLaunchKernelGGL(head_bias_partial_kernel, dim3(nblocks), dim3(256), 0, s, dhead, (float*)workspace, M, N, rows);
     FVA_LAUNCH_CHECK("head_bias_partial_kernel");
-    hipLaunchKernelGGL(head_bias_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, (const float*)workspace, grad_scale, dbias, N,
+    hipLaunchKernelGGL(head_bias_final_kernel, dim3(N), dim3(256), 0, s, (const float*)workspace, grad_scale, dbias, N,
                        nblocks, accumulate);
     FVA_LAUNCH_CHECK("head_bias_final_kernel");
     return FVA_OK;

@@ -164,12 +164,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int n, int nblocks, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// one block per weight element: 256 lanes share the per-block partials, fixed-order tree in LDS (deterministic)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int n,
+                                                                int nblocks, int accumulate) {
+    __shared__ float red[256];
+    const int i = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * n + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += slab[(int64_t)b * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[i] = accumulate ? dw[i] + red[0] : red[0];
 }
 
 constexpr int WGRAD_BLOCKS = 1024;
@@ -219,7 +227,7 @@ int fva_stem_wgrad(int dtype, const float* img, const void* dy, float* dw, int a
         return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad: bad dtype");
     FVA_LAUNCH_CHECK("stem_wgrad_kernel");
     const int n = Cout * Cin * 9;
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, grid, accumulate);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(n), dim3(256), 0, s, (const float*)workspace, dw, n, grid, accumulate);
     FVA_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
     return FVA_OK;
 }
