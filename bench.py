@@ -163,7 +163,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+            traffic = (json.load(open(tpath)).get(dom) or {}).get('bytes_per_launch')   # measured offline with PMC counters
         out = {
             'metric': METRIC, 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',

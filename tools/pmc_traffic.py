@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
+MI355X_MICROARCH.md section HBM prescribes).  Units: the counters are in KiB; on gfx950 FETCH_SIZE reports exactly
+half of a wide coalesced read, so it is doubled; WRITE_SIZE is exact.  (Check in this data: adam_kernel reads
+16 B and writes 12 B per parameter, 61.95 M parameters -> 991 / 743 MB; measured 2 x 495 / 743 MB.)
+
+usage: tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <out.md>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+CLASSES = {'conv_fwd': lambda n: 'igemm_kernel' in n and re.search(r'ELi0ELi\d+EEE', n),
+           'conv_dgrad': lambda n: 'igemm_kernel' in n and re.search(r'ELi1ELi\d+EEE', n),
+           'conv_wgrad': lambda n: 'wgrad_kernel' in n or 'wgrad_reduce_kernel' in n}
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            a = agg[r['Kernel_Name']]
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+    out, lines = {}, ['| kernel | launches | HBM read MB/launch (2 x FETCH_SIZE) | HBM write MB/launch |', '|---|---:|---:|---:|']
+    for n in sorted(f, key=lambda k: -(2 * f[k][1] + w.get(k, [0, 0])[1])):
+        cnt, tot = f[n]
+        wc, wt = w.get(n, [0, 0.0])
+        rd, wr = 2 * tot / cnt * 1024 / 1e6, (wt / wc * 1024 / 1e6 if wc else 0.0)
+        if rd + wr > 1.0:
+            lines.append(f"| `{re.sub(r'[(].*', '', n)[:70]}` | {cnt} | {rd:.1f} | {wr:.1f} |")
+    for cls, pred in CLASSES.items():
+        names = [n for n in f if pred(n)]
+        main_launches = sum(f[n][0] for n in names if 'reduce' not in n)
+        rd = sum(2 * f[n][1] for n in names) * 1024
+        wr = sum(w.get(n, [0, 0.0])[1] for n in names) * 1024
+        out[cls] = {'bytes_per_launch': round((rd + wr) / main_launches), 'read_bytes_per_launch': round(rd / main_launches),
+                    'write_bytes_per_launch': round(wr / main_launches), 'launches_profiled': main_launches,
+                    'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled (gfx950)'}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    open(sys.argv[4], 'w').write('# HBM traffic per launch (PMC), bench.py B=32 640x640 bf16, 3 steps\n\n' + '\n'.join(lines) +
+                                 '\n\nPer conv class (all tile variants pooled, per conv call):\n\n```\n' + json.dumps(out, indent=1) + '\n```\n')
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
