@@ -12,9 +12,13 @@
 // fp32 gradient.  Roofline: MFMA-bound (2*M*N*C*taps flop).
 //
 // Replaces the backward-weight of nn.Conv2d (reference classfication/models/darknet53.py:5-9 via autograd).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct WgradParams {
     const void* x;
@@ -31,6 +35,20 @@ struct WgradParams {
     int ntn, ntc, ksplit, mchunk;
     int tpt, ngroups;  // taps packed side by side in one column tile (thin layers: C < tile), tap groups
 };
+
+// ds_read_b64_tr_b16 as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever an LDS-DMA
+// is in flight, which would serialise the next tile's DMA with this tile's MFMAs.  The asm form is invisible to
+// that bookkeeping; its completion is awaited by hand (`s_waitcnt lgkmcnt(0)` + sched_barrier) before the MFMAs.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(uint32_t addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
@@ -82,9 +100,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int own_row = ((((lane & 15) >> 2) * 4 + w) * 4) + (lane & 3);
     const char* dy_base = (const char*)p.dy;
     const char* x_base = (const char*)p.x;
-    auto load_step = [&](int step, int stage) {
-        char* sA = smem + stage * STAGE;
-        char* sB = sA + OP_BYTES;
+    uint32_t nx_dy[4], nx_x[4];  // DMA byte offsets of the NEXT tile to issue (decoded one iteration ahead)
+    auto decode_step = [&](int step) {
         int m = mbeg + step * BKP + own_row;
         const bool live = m < mend;
         m = m < p.M ? m : p.M - 1;
@@ -98,10 +115,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         const uint32_t own_x = xpix * x_pixb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t doff = (uint32_t)__shfl((int)own_dy, i * 4 + lrow) + a_colb;
-            const uint32_t xoff = (uint32_t)__shfl((int)own_x, i * 4 + lrow) + b_colb;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + doff), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + xoff), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
+            nx_dy[i] = (uint32_t)__shfl((int)own_dy, i * 4 + lrow) + a_colb;
+            nx_x[i] = (uint32_t)__shfl((int)own_x, i * 4 + lrow) + b_colb;
+        }
+    };
+    auto issue_step = [&](int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + OP_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + nx_dy[i]), LDS_PTR(sA + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + nx_x[i]), LDS_PTR(sB + (i * 4 + w) * 1024), 16, 0, 0);
         }
     };
 
@@ -117,44 +141,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         for (int e = 0; e < 16; ++e) acc32[e] = 0.f;
     }
 
-    load_step(0, 0);
-    for (int st = 0; st < steps; ++st) {
-        __syncthreads();
-        const char* sA = smem + (st & 1) * STAGE;
-        const char* sB = sA + OP_BYTES;
-        if constexpr (IS_BF16) {
-            // transposed read: lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a
-            // 4-row x 16-column block and receives column (lane&15) of the 4 rows.  All fragments of the tile are
-            // read BEFORE the next tile's DMA is issued: hipcc waits vmcnt(0) in front of a ds_read_tr that
-            // follows an LDS-DMA, which would serialise the DMA with the MFMAs.
-            const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-            using s16x8 = __attribute__((ext_vector_type(8))) short;
-            bf16x8 af[2][4], bfr[2][4];
+    decode_step(0);
+    issue_step(0);
+    if (steps > 1) decode_step(1);
+    if constexpr (IS_BF16) {
+        // lane-constant LDS addresses of the transposed reads (see the mapping note below); stage, operand and the
+        // 32-pixel half of the tile go into the instruction's immediate offset, so the loop does no address math
+        const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+        const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
+        uint32_t ra[2][4], rb[2][4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s16x4 la[2][4], lb[2][4];
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row = 8 * g + 4 * hh + q;                 // + 32 * kk
+            const int fr = (q << 2) | ((2 * g + hh) & 3);       // swizzle of that row (unchanged by + 32)
+            const int rbase = row * 256 + 8 * (pp & 1);
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int row = kk * 32 + 8 * g + 4 * hh + q;
-                    const int fr = (q << 2) | ((2 * g + hh) & 3);
-                    const int rbase = row * 256 + 8 * (pp & 1);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int cha = wr * 8 + t * 2 + (pp >> 1);
-                        const int chb = wc * 8 + t * 2 + (pp >> 1);
-                        la[hh][t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sA + rbase + ((cha ^ fr) << 4)));
-                        lb[hh][t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)LDS_PTR(sB + rbase + ((chb ^ fr) << 4)));
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {  // k = 8g + (0..3 | 4..7): concatenate the two transposed reads
-                    af[kk][t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(la[0][t], la[1][t], 0, 1, 2, 3, 4, 5, 6, 7));
-                    bfr[kk][t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lb[0][t], lb[1][t], 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+            for (int t = 0; t < 4; ++t) {
+                ra[hh][t] = lds0 + rbase + (((wr * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
+                rb[hh][t] = lds0 + rbase + (((wc * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
             }
-            if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
+        }
+        // transposed read: lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a 4-row x 16-column
+        // block and receives column (lane&15) of the 4 rows; two reads (k = 8g+0..3, 8g+4..7) make one MFMA fragment
+        auto iteration = [&](int st, auto stage_tag) {
+            constexpr int SO = decltype(stage_tag)::value * STAGE;
+            wait_vm0();
+            __builtin_amdgcn_s_barrier();
+            if (st + 1 < steps) issue_step(decltype(stage_tag)::value ^ 1);
+            bf16x8 af[2][4], bfr[2][4];
+#define FVA_TR_PAIR(KK, TT)                                                                                            \
+    af[KK][TT] = cat8(tr_read<SO + KK * 8192>(ra[0][TT]), tr_read<SO + KK * 8192>(ra[1][TT]));                           \
+    bfr[KK][TT] = cat8(tr_read<SO + OP_BYTES + KK * 8192>(rb[0][TT]), tr_read<SO + OP_BYTES + KK * 8192>(rb[1][TT]));
+            FVA_TR_PAIR(0, 0) FVA_TR_PAIR(0, 1) FVA_TR_PAIR(0, 2) FVA_TR_PAIR(0, 3)
+            FVA_TR_PAIR(1, 0) FVA_TR_PAIR(1, 1) FVA_TR_PAIR(1, 2) FVA_TR_PAIR(1, 3)
+#undef FVA_TR_PAIR
+            if (st + 2 < steps) decode_step(st + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -162,8 +185,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
                         acc16[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][nt], bfr[kk][ct], acc16[nt][ct], 0, 0, 0);
-        } else {
-            if (st + 1 < steps) load_step(st + 1, (st + 1) & 1);
+        };
+        for (int st = 0; st < steps; st += 2) {
+            iteration(st, std::integral_constant<int, 0>{});
+            if (st + 1 < steps) iteration(st + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int st = 0; st < steps; ++st) {
+            __syncthreads();
+            if (st + 1 < steps) {
+                issue_step((st + 1) & 1);
+                if (st + 2 < steps) decode_step(st + 2);
+            }
+            const char* sA = smem + (st & 1) * STAGE;
+            const char* sB = sA + OP_BYTES;
             const int r = lane & 31, h = lane >> 5;
             const float* fa = (const float*)sA + wr * 32 + r;
             const float* fb = (const float*)sB + wc * 32 + r;
