@@ -143,6 +143,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
+        host_s = time.perf_counter() - t0          # time the host needed to ISSUE the steps (no sync inside a step)
         fence()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -179,7 +180,7 @@ def main():
             'kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / args.steps, 3),
                             'launches_per_step': v['launches'] // args.steps} for k, v in summ.items()},
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
-            'loss': round(final_loss, 5),
+            'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
         }
         if args.shapes:
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):

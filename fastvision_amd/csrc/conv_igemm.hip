@@ -126,10 +126,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         b_ptr[i] = (const T*)p.wt + (int64_t)n * p.C + sub * EPC;
     }
 
-    // per-k-tile element offsets (A: tap pixel offset * C + channel slice; B: tap matrix + channel slice),
-    // tabulated once in LDS so the k loop does no division and no dynamic kernarg indexing
+    // per-k-tile element offsets (A: tap pixel offset * C + channel slice; B: tap matrix + channel slice).  Wide
+    // tiles tabulate them once in LDS (no division / dynamic kernarg indexing in the loop); the thin 256x64 tile
+    // keeps its LDS at exactly 2 x 40 KiB so that two blocks fit a CU, and selects the tap with a short unrolled scan.
+    constexpr bool USE_KTAB = BN >= 128;
     int* ktab = (int*)(smem + NSTAGE * STAGE);
-    {
+    if constexpr (USE_KTAB) {
         const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
         for (int e = tid; e < nent; e += NT) {
             int t, kk;
@@ -142,13 +144,28 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             ktab[2 * e] = tp * p.C + kk * BK;
             ktab[2 * e + 1] = tw * p.N * p.C + kk * BK;
         }
+        __syncthreads();
     }
-    __syncthreads();
+    int ld_tap = 0, ld_kk = 0;  // running (tap, k-slice) of the next tile to fetch (thin tile only)
     auto load_tile = [&](int kt, int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + A_BYTES;
-        const int e = p.halfrow ? 2 * kt + tapsel : kt;
-        const int aoff = ktab[2 * e], boff = ktab[2 * e + 1];
+        int aoff, boff;
+        if constexpr (USE_KTAB) {
+            const int e = p.halfrow ? 2 * kt + tapsel : kt;
+            aoff = ktab[2 * e];
+            boff = ktab[2 * e + 1];
+        } else {
+            const int t = p.halfrow ? ld_tap + tapsel : ld_tap;
+            int tp = 0, tw = 0;
+#pragma unroll
+            for (int i = 0; i < MAX_TAPS; ++i)
+                if (i == t) { tp = p.tap_pix[i]; tw = p.tap_w[i]; }
+            aoff = tp * p.C + ld_kk * BK;
+            boff = tw * p.N * p.C + ld_kk * BK;
+            if (p.halfrow) ld_tap += 2;
+            else if (++ld_kk == p.kt_per_tap) { ld_kk = 0; ++ld_tap; }
+        }
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(sA + (i * NW + w) * 1024), 16, 0, 0);
@@ -349,7 +366,7 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
     q.nblocks = cdiv(p.N, BN);
-    const int smem = NSTAGE * (BM + BN) * 128 + 4096;  // stages + k-tile offset table
+    const int smem = NSTAGE * (BM + BN) * 128 + (BN >= 128 ? 4096 : 0);  // stages (+ k-tile offset table, wide tiles)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -293,13 +293,22 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     pl.tpt = (d->Cin < pl.tile && pl.tile % d->Cin == 0 && pl.ntaps > 1) ? pl.tile / d->Cin : 1;
     pl.ngroups = cdiv(pl.ntaps, pl.tpt);
     const int tiles = pl.ntn * pl.ntc * pl.ngroups;
-    int ks = cdiv(512, tiles);   // ~2 resident blocks per CU; fewer partial tiles to write and reduce
-    const int max_by_m = cdiv(pl.M, 256);
-    if (ks > max_by_m) ks = max_by_m;
+    // Split-K factor: 256 CUs x 2 resident blocks (64 KiB LDS each) = 512 slots.  The launch takes about
+    // ceil(blocks / 512) rounds of blocks whose length is ~ 1/ks, plus a small cost per extra partial tile to
+    // write and reduce; pick the ks that minimises that (e.g. 18 tiles -> 28 x 18 = 504 blocks, one full round).
+    const int max_by_m = cdiv(pl.M, 512) > 0 ? cdiv(pl.M, 512) : 1;
     const int64_t per = (int64_t)pl.ntaps * d->Cout * d->Cin * 4;
-    const int64_t max_by_ws = (512ll << 20) / per;
-    if (ks > max_by_ws) ks = (int)max_by_ws;
-    if (ks < 1) ks = 1;
+    int64_t max_by_ws = (512ll << 20) / per;
+    int kmax = max_by_m < 96 ? max_by_m : 96;
+    if (kmax > max_by_ws) kmax = (int)max_by_ws;
+    if (kmax < 1) kmax = 1;
+    int ks = 1;
+    double best = 1e30;
+    for (int k = 1; k <= kmax; ++k) {
+        const int rounds = cdiv((int64_t)tiles * k, 512);
+        const double cost = (double)rounds / k + 0.002 * k;
+        if (cost < best - 1e-12) { best = cost; ks = k; }
+    }
     pl.mchunk = cdiv(cdiv(pl.M, ks), 64) * 64;
     pl.ksplit = cdiv(pl.M, pl.mchunk);
     return FVA_OK;
