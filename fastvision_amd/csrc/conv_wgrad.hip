@@ -293,21 +293,24 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     pl.tpt = (d->Cin < pl.tile && pl.tile % d->Cin == 0 && pl.ntaps > 1) ? pl.tile / d->Cin : 1;
     pl.ngroups = cdiv(pl.ntaps, pl.tpt);
     const int tiles = pl.ntn * pl.ntc * pl.ngroups;
-    // Split-K factor: 256 CUs x 2 resident blocks (64 KiB LDS each) = 512 slots.  The launch takes about
-    // ceil(blocks / 512) rounds of blocks whose length is ~ 1/ks, plus a small cost per extra partial tile to
-    // write and reduce; pick the ks that minimises that (e.g. 18 tiles -> 28 x 18 = 504 blocks, one full round).
-    const int max_by_m = cdiv(pl.M, 512) > 0 ? cdiv(pl.M, 512) : 1;
+    // Split-K factor: 256 CUs x 2 resident blocks (64 KiB LDS each) = 512 slots.  Model: the launch takes
+    // ceil(blocks / 512) rounds of blocks that each do 1/ks of a tile's pixels (t_full: one block doing a whole tile at
+    // ~1.6 TFLOP/s per resident block), plus ks partial tiles to write and re-read at ~3 TB/s.  E.g. 18 tiles of a
+    // 128->256 3x3 layer -> ks = 28 (504 blocks, one full round); a 1-tile 1x1 layer -> ks = 512.
+    const int max_by_m = cdiv(pl.M, 256) > 0 ? cdiv(pl.M, 256) : 1;
     const int64_t per = (int64_t)pl.ntaps * d->Cout * d->Cin * 4;
     int64_t max_by_ws = (512ll << 20) / per;
-    int kmax = max_by_m < 96 ? max_by_m : 96;
+    int kmax = max_by_m < 1024 ? max_by_m : 1024;
     if (kmax > max_by_ws) kmax = (int)max_by_ws;
     if (kmax < 1) kmax = 1;
+    const double t_full = 2.0 * pl.M * pl.tile * pl.tile / 1.6e12;
+    const double t_slab = (double)per * 2.0 / 3.0e12 + 0.05e-6;
     int ks = 1;
     double best = 1e30;
     for (int k = 1; k <= kmax; ++k) {
         const int rounds = cdiv((int64_t)tiles * k, 512);
-        const double cost = (double)rounds / k + 0.002 * k;
-        if (cost < best - 1e-12) { best = cost; ks = k; }
+        const double cost = rounds * t_full / k + k * t_slab;
+        if (cost < best * (1.0 - 1e-9)) { best = cost; ks = k; }
     }
     pl.mchunk = cdiv(cdiv(pl.M, ks), 64) * 64;
     pl.ksplit = cdiv(pl.M, pl.mchunk);

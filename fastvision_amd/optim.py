@@ -38,9 +38,14 @@ class FusedAdam(torch.optim.Optimizer):
             ptrs = [p.data_ptr() for p in ps] + [p.grad.data_ptr() for p in ps] + \
                    [self.state[p]['exp_avg'].data_ptr() for p in ps] + [self.state[p]['exp_avg_sq'].data_ptr() for p in ps]
             dev = ps[0].device
-            tab = torch.tensor(ptrs, dtype=torch.int64).to(dev)
-            sizes = torch.tensor([p.numel() for p in ps], dtype=torch.int64).to(dev)
-            hit = (key, tab, sizes, n, max(p.numel() for p in ps))
+            # gradients are fresh tensors every step, so this small table is re-uploaded every step: pinned staging +
+            # non_blocking keeps the upload asynchronous (a pageable .to(device) would stall the host on the stream)
+            host = torch.tensor(ptrs + [p.numel() for p in ps], dtype=torch.int64)
+            if dev.type == 'cuda':
+                host = host.pin_memory()
+            both = host.to(dev, non_blocking=True)
+            tab, sizes = both[:4 * n], both[4 * n:]
+            hit = (key, tab, sizes, n, max(p.numel() for p in ps), host)
             self._tables[gi] = hit
         return ps, hit
 
@@ -53,7 +58,7 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue
-            ps, (_, tab, sizes, n, mx) = self._table(gi, group)
+            ps, (_, tab, sizes, n, mx, _keep) = self._table(gi, group)
             if not ps[0].is_cuda:
                 raise RuntimeError('FusedAdam: parameters must live on the GPU (no CPU path)')
             step = self.state[ps[0]]['step'] + 1
