@@ -11,9 +11,12 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_f(float u) { return u * sigmoidf_(u); }
+// sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE divide: these kernels are HBM-bound and the
+// divide sequence (~10 VALU ops per element) was competing with the memory pipeline
+__device__ __forceinline__ float sigm_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_f(float u) { return u * sigm_fast(u); }
 __device__ __forceinline__ float silu_grad(float u) {
-    const float s = sigmoidf_(u);
+    const float s = sigm_fast(u);
     return s * (1.f + u * (1.f - s));
 }
 
@@ -110,35 +113,46 @@ __device__ __forceinline__ bool halo_decode(const HaloIdx& h, uint32_t idx, int&
     return y >= 0 && y < h.H && x >= 0 && x < h.W;
 }
 
+// One block per row of the padded output buffer (blockIdx.x = b * Hp + yp): no index division per chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const T* __restrict__ res,
                                                             int res_pad, T* __restrict__ z, const HaloIdx h) {
     constexpr int EPC = Vec16<T>::N;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < h.total; i += (int64_t)gridDim.x * blockDim.x) {
-        int b, yy, xx, cc;
+    const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
+    const int yy = yp - h.pad;
+    const bool row_in = yy >= 0 && yy < h.H;
+    const int row_chunks = h.Wp * h.cpp;
+    T* zrow = z + (int64_t)blockIdx.x * row_chunks * EPC;
+    const T* yrow = y + ((int64_t)b * h.H + yy) * h.W * h.C;
+    const int rW = h.W + 2 * res_pad;
+    const T* rrow = res ? res + (((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + res_pad) * h.C : nullptr;
+    const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);  // cpp is a power of two (BN channel counts)
+    for (int i = threadIdx.x; i < row_chunks; i += 256) {
+        const int xp = i >> cshift, cc = i & cmask;
+        const int xx = xp - h.pad;
         Vec16<T> out;
-        if (halo_decode(h, (uint32_t)i, b, yy, xx, cc)) {
-            const int64_t m = ((int64_t)b * h.H + yy) * h.W + xx;
-            const Vec16<T> v = *(const Vec16<T>*)(y + m * h.C + cc * EPC);
+        if (row_in && xx >= 0 && xx < h.W) {
+            const Vec16<T> v = *(const Vec16<T>*)(yrow + (int64_t)xx * h.C + cc * EPC);
             Vec16<T> r;
-            if (res) {
-                const int rW = h.W + 2 * res_pad;
-                const int64_t rp = ((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + xx + res_pad;
-                r = *(const Vec16<T>*)(res + rp * h.C + cc * EPC);
-            }
+            if (res) r = *(const Vec16<T>*)(rrow + (int64_t)xx * h.C + cc * EPC);
+            const f32x4* sc4 = (const f32x4*)(scale + cc * EPC);
+            const f32x4* sh4 = (const f32x4*)(shift + cc * EPC);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int c = cc * EPC + e;
-                float o = silu_f(v.get(e) * scale[c] + shift[c]);
-                if (res) o += r.get(e);
-                out.set(e, o);
+            for (int q = 0; q < EPC / 4; ++q) {
+                const f32x4 sc = sc4[q], sh = sh4[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float o = silu_f(v.get(q * 4 + e) * sc[e] + sh[e]);
+                    if (res) o += r.get(q * 4 + e);
+                    out.set(q * 4 + e, o);
+                }
             }
         } else {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
         }
-        *(Vec16<T>*)(z + i * EPC) = out;
+        *(Vec16<T>*)(zrow + (int64_t)i * EPC) = out;
     }
 }
 
@@ -220,13 +234,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h) {
     constexpr int EPC = Vec16<T>::N;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < h.total; i += (int64_t)gridDim.x * blockDim.x) {
-        int b, yy, xx, cc;
+    const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
+    const int yy = yp - h.pad;
+    const bool row_in = yy >= 0 && yy < h.H;
+    const int row_chunks = h.Wp * h.cpp;
+    T* orow = dy + (int64_t)blockIdx.x * row_chunks * EPC;
+    const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
+    const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);
+    for (int i = threadIdx.x; i < row_chunks; i += 256) {
+        const int xp = i >> cshift, cc = i & cmask;
+        const int xx = xp - h.pad;
         Vec16<T> out;
-        if (halo_decode(h, (uint32_t)i, b, yy, xx, cc)) {
-            const int64_t m = ((int64_t)b * h.H + yy) * h.W + xx;
-            const Vec16<T> g = *(const Vec16<T>*)(dz + m * h.C + cc * EPC);
-            const Vec16<T> v = *(const Vec16<T>*)(y + m * h.C + cc * EPC);
+        if (row_in && xx >= 0 && xx < h.W) {
+            const int64_t off = (m0 + xx) * h.C + cc * EPC;
+            const Vec16<T> g = *(const Vec16<T>*)(dz + off);
+            const Vec16<T> v = *(const Vec16<T>*)(y + off);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const int c = cc * EPC + e;
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
         }
-        *(Vec16<T>*)(dy + i * EPC) = out;
+        *(Vec16<T>*)(orow + (int64_t)i * EPC) = out;
     }
 }
 
@@ -389,12 +411,13 @@ int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float*
     if (!y || !scale || !shift || !z) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: null pointer");
     const HaloIdx h = make_halo(B, H, W, C, z_pad, dtype == FVA_BF16 ? 8 : 4);
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: tensor too large");
+    if (h.cpp & (h.cpp - 1)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: C=%d must be a power of two", C);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_silu_apply_kernel<bf16_t>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+        hipLaunchKernelGGL(bn_silu_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
                            (const bf16_t*)residual, res_pad, (bf16_t*)z, h);
     else
-        hipLaunchKernelGGL(bn_silu_apply_kernel<float>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const float*)y, scale, shift,
+        hipLaunchKernelGGL(bn_silu_apply_kernel<float>, dim3(B * h.Hp), dim3(256), 0, s, (const float*)y, scale, shift,
                            (const float*)residual, res_pad, (float*)z, h);
     FVA_LAUNCH_CHECK("bn_silu_apply_kernel");
     return FVA_OK;
@@ -454,12 +477,13 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
     if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !coef || !dy) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: null pointer");
     const HaloIdx h = make_halo(B, H, W, C, dy_pad, dtype == FVA_BF16 ? 8 : 4);
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
+    if (h.cpp & (h.cpp - 1)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two", C);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
                            scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(h.total)), dim3(256), 0, s, (const float*)dz, (const float*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(B * h.Hp), dim3(256), 0, s, (const float*)dz, (const float*)y,
                            scale, shift, save_mean, save_rstd, coef, (float*)dy, h);
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return FVA_OK;
