@@ -128,25 +128,27 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
     const int rW = h.W + 2 * res_pad;
     const T* rrow = res ? res + (((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + res_pad) * h.C : nullptr;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);  // cpp is a power of two (BN channel counts)
+    // cpp divides 256, so a lane keeps the same channel chunk for the whole row: its coefficients live in registers
+    const int cc = threadIdx.x & cmask;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale[cc * EPC + e];
+        sh[e] = shift[cc * EPC + e];
+    }
     for (int i = threadIdx.x; i < row_chunks; i += 256) {
-        const int xp = i >> cshift, cc = i & cmask;
+        const int xp = i >> cshift;
         const int xx = xp - h.pad;
         Vec16<T> out;
         if (row_in && xx >= 0 && xx < h.W) {
             const Vec16<T> v = *(const Vec16<T>*)(yrow + (int64_t)xx * h.C + cc * EPC);
             Vec16<T> r;
             if (res) r = *(const Vec16<T>*)(rrow + (int64_t)xx * h.C + cc * EPC);
-            const f32x4* sc4 = (const f32x4*)(scale + cc * EPC);
-            const f32x4* sh4 = (const f32x4*)(shift + cc * EPC);
 #pragma unroll
-            for (int q = 0; q < EPC / 4; ++q) {
-                const f32x4 sc = sc4[q], sh = sh4[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float o = silu_f(v.get(q * 4 + e) * sc[e] + sh[e]);
-                    if (res) o += r.get(q * 4 + e);
-                    out.set(q * 4 + e, o);
-                }
+            for (int e = 0; e < EPC; ++e) {
+                float o = silu_f(v.get(e) * sc[e] + sh[e]);
+                if (res) o += r.get(e);
+                out.set(e, o);
             }
         } else {
 #pragma unroll
@@ -241,8 +243,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     T* orow = dy + (int64_t)blockIdx.x * row_chunks * EPC;
     const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);
+    // lane-constant channel chunk (cpp divides 256): dY = a*dU + k1*y + k2 with k1 = coefB*rstd, k2 = coefC - k1*mean
+    const int cc = threadIdx.x & cmask;
+    float sc[EPC], sh[EPC], ka[EPC], k1[EPC], k2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cc * EPC + e;
+        sc[e] = scale[c];
+        sh[e] = shift[c];
+        ka[e] = coef[c];
+        k1[e] = coef[h.C + c] * rstd[c];
+        k2[e] = coef[2 * h.C + c] - k1[e] * mean[c];
+    }
     for (int i = threadIdx.x; i < row_chunks; i += 256) {
-        const int xp = i >> cshift, cc = i & cmask;
+        const int xp = i >> cshift;
         const int xx = xp - h.pad;
         Vec16<T> out;
         if (row_in && xx >= 0 && xx < h.W) {
@@ -251,11 +265,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const Vec16<T> v = *(const Vec16<T>*)(y + off);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const int c = cc * EPC + e;
                 const float yv = v.get(e);
-                const float du = g.get(e) * silu_grad(yv * scale[c] + shift[c]);
-                const float xh = (yv - mean[c]) * rstd[c];
-                out.set(e, coef[c] * du + coef[h.C + c] * xh + coef[2 * h.C + c]);
+                const float du = g.get(e) * silu_grad(yv * sc[e] + sh[e]);
+                out.set(e, ka[e] * du + k1[e] * yv + k2[e]);
             }
         } else {
 #pragma unroll
@@ -411,7 +423,7 @@ int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float*
     if (!y || !scale || !shift || !z) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: null pointer");
     const HaloIdx h = make_halo(B, H, W, C, z_pad, dtype == FVA_BF16 ? 8 : 4);
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: tensor too large");
-    if (h.cpp & (h.cpp - 1)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: C=%d must be a power of two", C);
+    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(bn_silu_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
@@ -477,7 +489,7 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
     if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !coef || !dy) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: null pointer");
     const HaloIdx h = make_halo(B, H, W, C, dy_pad, dtype == FVA_BF16 ? 8 : 4);
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
-    if (h.cpp & (h.cpp - 1)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two", C);
+    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
