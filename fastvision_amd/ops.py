@@ -153,6 +153,20 @@ class _Saved:
     pass
 
 
+# wgrad is off the critical path of backward (only the optimizer needs it): it is launched on a side stream,
+# concurrently with the same layer's dgrad, so the two fill each other's partially occupied last rounds.
+import os as _os
+_side_streams = {}
+OVERLAP_WGRAD = _os.environ.get('FVA_WGRAD_STREAM', '1') != '0'
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
     """SiLU(BN(conv(x))) [+ residual].  x: logical [B,Cin,H,W]; x_ptr/x_pad describe its halo buffer.
     Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape."""
@@ -211,12 +225,23 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
               _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+    overlap = OVERLAP_WGRAD and need_dx
+    if overlap:
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)                           # dY (and everything before it) is ready
+        with torch.cuda.stream(side):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+        dw.record_stream(side)
+    else:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
         _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(s.wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
+    if overlap:
+        main.wait_stream(side)                           # dw is complete before anyone downstream can read it
     return dx, dw, dgamma, dbeta
 
 
