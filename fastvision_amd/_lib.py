@@ -23,6 +23,11 @@ class HeadLevel(C.Structure):
                 ('anchor_w', C.c_float * 8), ('anchor_h', C.c_float * 8), ('stride', C.c_float)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('w_fwd', C.c_void_p), ('w_dgrad', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype')]
+
+
 class MatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
 
@@ -37,6 +42,7 @@ PROTOTYPES = {
     'fva_version': (_I, []),
     'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
     'fva_conv_packed_elems': (_L, [_D, _I]),
+    'fva_conv_pack_weights_multi': (_I, [_P, _I, _L, _P]),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),

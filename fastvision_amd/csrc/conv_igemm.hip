@@ -261,11 +261,20 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             float s1[NT], s2[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
-            foreach_acc(acc, lane, [&](int row, int, int nt, float v) {
-                const float x = (m0 + wrow0 + row < p.M) ? to_f(from_f<T>(v)) : 0.f;  // stats of the stored values
-                s1[nt] += x;
-                s2[nt] += x * x;
-            });
+            // statistics of the fp32 accumulators (the bf16 rounding of the stored tile is zero-mean, 2^-9 relative:
+            // far below the batch-statistics noise); full tiles take the mask-free path
+            if (m0 + BM <= p.M) {
+                foreach_acc(acc, lane, [&](int, int, int nt, float v) {
+                    s1[nt] += v;
+                    s2[nt] += v * v;
+                });
+            } else {
+                foreach_acc(acc, lane, [&](int row, int, int nt, float v) {
+                    const float x = (m0 + wrow0 + row < p.M) ? v : 0.f;
+                    s1[nt] += x;
+                    s2[nt] += x * x;
+                });
+            }
             float* red = (float*)smem;  // [2][BM/64][BN]
             constexpr int WMc = BM / 64;
 #pragma unroll
@@ -472,6 +481,27 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void
     }
 }
 
+// all conv layers of a model in ONE launch: blockIdx.y selects the table entry (one per layer)
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_entry* __restrict__ table) {
+    const fva_pack_entry e = table[blockIdx.y];
+    const int kk = e.ksize * e.ksize;
+    const int64_t total = (int64_t)(e.taps_fwd > e.taps_dgrad ? e.taps_fwd : e.taps_dgrad) * e.Cout * e.Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % e.Cin);
+        const int co = (int)((i / e.Cin) % e.Cout);
+        const int t = (int)(i / ((int64_t)e.Cin * e.Cout));
+        const float v = t < kk ? e.w[((int64_t)co * e.Cin + ci) * kk + t] : 0.f;
+        if (e.w_fwd && t < e.taps_fwd) {
+            const int64_t o = ((int64_t)t * e.Cout + co) * e.Cin + ci;
+            if (e.dtype == FVA_BF16) ((bf16_t*)e.w_fwd)[o] = (bf16_t)v; else ((float*)e.w_fwd)[o] = v;
+        }
+        if (e.w_dgrad && t < e.taps_dgrad) {
+            const int64_t o = ((int64_t)t * e.Cin + ci) * e.Cout + co;
+            if (e.dtype == FVA_BF16) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+        }
+    }
+}
+
 int packed_taps(const fva_conv_desc* d, int for_dgrad) {
     const int kk = d->ksize * d->ksize;
     const int C = for_dgrad ? d->Cout : d->Cin;
@@ -497,6 +527,15 @@ int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, v
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_dgrad, d->Cout,
                        d->Cin, d->ksize * d->ksize, tf, td, d->dtype == FVA_BF16 ? 1 : 0);
     FVA_LAUNCH_CHECK("pack_weights_kernel");
+    return FVA_OK;
+}
+
+int fva_conv_pack_weights_multi(const fva_pack_entry* table_dev, int32_t n, int64_t max_elems, void* stream) {
+    if (!table_dev || n < 1 || max_elems < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights_multi: bad argument");
+    int64_t gx = (max_elems + 1023) / 1024;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    FVA_LAUNCH_CHECK("pack_weights_multi_kernel");
     return FVA_OK;
 }
 

@@ -133,6 +133,52 @@ class _BNState:
         self.eps = bn.eps
 
 
+class _PackRegistry:
+    """All conv weights seen so far, so that the per-step re-pack (fp32 OIHW -> MFMA operand layouts) is ONE launch.
+
+    The first stale weight met in a step triggers ``fva_conv_pack_weights_multi`` over every registered layer (the
+    optimizer updates them all at once); the other layers then find their cache fresh."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> (weakref(weight), desc fields, wf, wd); one entry per parameter
+        self.table = None
+
+    def add(self, weight, desc, wf, wd):
+        import weakref
+        self.entries[id(weight)] = (weakref.ref(weight), (desc.Cout, desc.Cin, desc.ksize, desc.dtype), wf, wd)
+        self.table = None
+
+    def repack_all(self, device):
+        dead = [k for k, (r, *_) in self.entries.items() if r() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.table = None
+        live = [(r(), m, wf, wd) for r, m, wf, wd in self.entries.values() if r().device == device]
+        if not live:
+            return
+        if self.table is None or self.table[0] != len(live) or self.table[3] != device:
+            arr = (_lib.PackEntry * len(live))()
+            mx = 0
+            for i, (w, (co, ci, k, dt), wf, wd) in enumerate(live):
+                e = arr[i]
+                e.w, e.w_fwd, e.w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
+                e.Cout, e.Cin, e.ksize, e.dtype = co, ci, k, dt
+                e.taps_fwd, e.taps_dgrad = wf.numel() // (co * ci), wd.numel() // (co * ci)
+                mx = max(mx, wf.numel(), wd.numel())
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            self.table = (len(live), raw, mx, device, [w.data_ptr() for w, *_ in live])
+        if self.table[4] != [w.data_ptr() for w, *_ in live]:      # a parameter moved: rebuild
+            self.table = None
+            return self.repack_all(device)
+        _lib.call('fva_conv_pack_weights_multi', _p(self.table[1]), self.table[0], self.table[2], _stream())
+        for w, (co, ci, k, dt), wf, wd in live:
+            w._fva_packed = ((w._version, w.data_ptr(), dt), wf, wd)
+
+
+_registry = _PackRegistry()
+
+
 def packed_weights(weight, desc, dtype, cache=True):
     """(w_fwd, w_dgrad) in the MFMA operand layouts.  The pair is cached ON the parameter object and re-packed
     only when its autograd version counter (bumped by every in-place update, incl. FusedAdam) or data moved."""
@@ -140,12 +186,19 @@ def packed_weights(weight, desc, dtype, cache=True):
     hit = getattr(weight, '_fva_packed', None) if cache else None
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
+    if hit is not None and hit[0][1:] == key[1:] and isinstance(weight, torch.nn.Parameter):
+        _registry.repack_all(weight.device)            # stale registered parameter: refresh every layer in one launch
+        hit = weight._fva_packed
+        if hit[0] == key:
+            return hit[1], hit[2]
     lib = _lib.load()
     wf = torch.empty(lib.fva_conv_packed_elems(C.byref(desc), 0), dtype=dtype, device=weight.device)
     wd = torch.empty(lib.fva_conv_packed_elems(C.byref(desc), 1), dtype=dtype, device=weight.device)
     _lib.call('fva_conv_pack_weights', C.byref(desc), _p(weight), _p(wf), _p(wd), _stream())
     if cache:
         weight._fva_packed = (key, wf, wd)
+        if isinstance(weight, torch.nn.Parameter):
+            _registry.add(weight, desc, wf, wd)
     return wf, wd
 
 

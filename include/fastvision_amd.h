@@ -62,6 +62,15 @@ typedef struct {
  * Either output may be NULL.  Sizes in elements: fva_conv_packed_elems(). */
 int fva_conv_pack_weights(const fva_conv_desc* d, const float* w_oihw, void* w_fwd, void* w_dgrad, void* stream);
 int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad);
+/* The same for every conv layer of a model in ONE launch (after each optimizer step): `table` is a DEVICE array of n
+ * entries; taps_fwd / taps_dgrad = fva_conv_packed_elems(...) / (Cout*Cin); max_elems = largest taps*Cout*Cin. */
+typedef struct {
+    const float* w;       /* fp32 OIHW master weight */
+    void* w_fwd;          /* [taps_fwd][Cout][Cin]   (may be NULL) */
+    void* w_dgrad;        /* [taps_dgrad][Cin][Cout] (may be NULL) */
+    int32_t Cout, Cin, ksize, taps_fwd, taps_dgrad, dtype;
+} fva_pack_entry;
+int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t max_elems, void* stream);
 
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
