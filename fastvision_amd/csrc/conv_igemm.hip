@@ -485,11 +485,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_entry* __restrict__ table) {
     const fva_pack_entry e = table[blockIdx.y];
     const int kk = e.ksize * e.ksize;
-    const int64_t total = (int64_t)(e.taps_fwd > e.taps_dgrad ? e.taps_fwd : e.taps_dgrad) * e.Cout * e.Cin;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % e.Cin);
-        const int co = (int)((i / e.Cin) % e.Cout);
-        const int t = (int)(i / ((int64_t)e.Cin * e.Cout));
+    const int total = (e.taps_fwd > e.taps_dgrad ? e.taps_fwd : e.taps_dgrad) * e.Cout * e.Cin;   // < 2^31
+    if ((int)(blockIdx.x * blockDim.x) >= total) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % e.Cin;
+        const int co = (i / e.Cin) % e.Cout;
+        const int t = i / (e.Cin * e.Cout);
         const float v = t < kk ? e.w[((int64_t)co * e.Cin + ci) * kk + t] : 0.f;
         if (e.w_fwd && t < e.taps_fwd) {
             const int64_t o = ((int64_t)t * e.Cout + co) * e.Cin + ci;
@@ -532,8 +533,8 @@ int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, v
 
 int fva_conv_pack_weights_multi(const fva_pack_entry* table_dev, int32_t n, int64_t max_elems, void* stream) {
     if (!table_dev || n < 1 || max_elems < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights_multi: bad argument");
-    int64_t gx = (max_elems + 1023) / 1024;
-    if (gx > 64) gx = 64;
+    int64_t gx = (max_elems + 2047) / 2048;   // small layers leave most of their blocks idle; large ones need them all
+    if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, table_dev);
     FVA_LAUNCH_CHECK("pack_weights_multi_kernel");
     return FVA_OK;
