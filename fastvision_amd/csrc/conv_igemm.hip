@@ -481,25 +481,49 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void
     }
 }
 
-// all conv layers of a model in ONE launch: blockIdx.y selects the table entry (one per layer)
+// All conv layers of a model in ONE launch: blockIdx.y selects the table entry (one per layer); each block walks
+// 32 (Cout) x 32 (Cin) tiles of that layer.  A tile's k*k taps are read as contiguous runs of the OIHW source,
+// staged in LDS and written out as 64-byte (bf16) rows of both operand layouts.
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_entry* __restrict__ table) {
+    __shared__ float tile[32][32 * 9 + 1];
     const fva_pack_entry e = table[blockIdx.y];
     const int kk = e.ksize * e.ksize;
-    const int total = (e.taps_fwd > e.taps_dgrad ? e.taps_fwd : e.taps_dgrad) * e.Cout * e.Cin;   // < 2^31
-    if ((int)(blockIdx.x * blockDim.x) >= total) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int ci = i % e.Cin;
-        const int co = (i / e.Cin) % e.Cout;
-        const int t = i / (e.Cin * e.Cout);
-        const float v = t < kk ? e.w[((int64_t)co * e.Cin + ci) * kk + t] : 0.f;
-        if (e.w_fwd && t < e.taps_fwd) {
-            const int64_t o = ((int64_t)t * e.Cout + co) * e.Cin + ci;
-            if (e.dtype == FVA_BF16) ((bf16_t*)e.w_fwd)[o] = (bf16_t)v; else ((float*)e.w_fwd)[o] = v;
+    const int tco = (e.Cout + 31) / 32, tci = (e.Cin + 31) / 32;
+    const bool bf = e.dtype == FVA_BF16;
+    for (int tl = blockIdx.x; tl < tco * tci; tl += gridDim.x) {
+        const int co0 = (tl / tci) * 32, ci0 = (tl % tci) * 32;
+        const int ncol = (e.Cin - ci0 < 32 ? e.Cin - ci0 : 32) * kk;   // contiguous floats per co row
+        for (int i = threadIdx.x; i < 32 * 32 * kk; i += 256) {
+            const int r = i / (32 * kk), c = i - r * (32 * kk);
+            tile[r][c] = (co0 + r < e.Cout && c < ncol) ? e.w[((int64_t)(co0 + r) * e.Cin + ci0) * kk + c] : 0.f;
         }
-        if (e.w_dgrad && t < e.taps_dgrad) {
-            const int64_t o = ((int64_t)t * e.Cin + ci) * e.Cout + co;
-            if (e.dtype == FVA_BF16) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+        __syncthreads();
+        const int a = threadIdx.x >> 5, l = threadIdx.x & 31;        // 8 rows at a time, 32 lanes along the row
+        for (int t = 0; t < kk; ++t) {
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += 8) {
+                const int r = rr + a;
+                // forward layout [t][co][ci]: row = co, lanes along ci
+                if (e.w_fwd && co0 + r < e.Cout && ci0 + l < e.Cin) {
+                    const int64_t o = ((int64_t)t * e.Cout + co0 + r) * e.Cin + ci0 + l;
+                    const float v = tile[r][l * kk + t];
+                    if (bf) ((bf16_t*)e.w_fwd)[o] = (bf16_t)v; else ((float*)e.w_fwd)[o] = v;
+                }
+                // dgrad layout [t][ci][co]: row = ci, lanes along co
+                if (e.w_dgrad && ci0 + r < e.Cin && co0 + l < e.Cout) {
+                    const int64_t o = ((int64_t)t * e.Cin + ci0 + r) * e.Cout + co0 + l;
+                    const float v = tile[l][r * kk + t];
+                    if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                }
+            }
         }
+        __syncthreads();
+    }
+    // zero pad tap (bf16 half-row k-tiles): taps_* may exceed k*k by one
+    const int64_t cc = (int64_t)e.Cout * e.Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cc; i += (int64_t)gridDim.x * blockDim.x) {
+        if (e.w_fwd && e.taps_fwd > kk) { if (bf) ((bf16_t*)e.w_fwd)[kk * cc + i] = (bf16_t)0.f; else ((float*)e.w_fwd)[kk * cc + i] = 0.f; }
+        if (e.w_dgrad && e.taps_dgrad > kk) { if (bf) ((bf16_t*)e.w_dgrad)[kk * cc + i] = (bf16_t)0.f; else ((float*)e.w_dgrad)[kk * cc + i] = 0.f; }
     }
 }
 
@@ -533,8 +557,9 @@ int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, v
 
 int fva_conv_pack_weights_multi(const fva_pack_entry* table_dev, int32_t n, int64_t max_elems, void* stream) {
     if (!table_dev || n < 1 || max_elems < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights_multi: bad argument");
-    int64_t gx = (max_elems + 2047) / 2048;   // small layers leave most of their blocks idle; large ones need them all
-    if (gx > 1024) gx = 1024;
+    int64_t gx = (max_elems / 9 + 1023) / 1024;   // one block per 32x32 tile of the largest layer, at most 512
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, table_dev);
     FVA_LAUNCH_CHECK("pack_weights_multi_kernel");
     return FVA_OK;

@@ -220,3 +220,31 @@ def test_adam_matches_torch():
         assert torch.allclose(pg.cpu(), pr, rtol=1e-5, atol=1e-6)
     sd = o_gpu.state_dict()
     assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+
+
+@pytest.mark.parametrize('key', ['f32', 'bf16'])
+def test_multi_tensor_weight_pack_matches_single(key):
+    """fva_conv_pack_weights_multi (one launch for all layers) must produce exactly the per-layer packing."""
+    from fastvision_amd import _lib, ops
+    dtype = DT[key]
+    lib = _lib.load()
+    shapes = [(64, 32, 3), (32, 64, 1), (255, 128, 1), (128, 64, 3), (48, 40, 3)]
+    g = torch.Generator().manual_seed(9)
+    ws = [torch.randn(co, ci, k, k, generator=g).to(dev()) for co, ci, k in shapes]
+    arr = (_lib.PackEntry * len(ws))()
+    singles, multis, mx = [], [], 0
+    for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
+        d = _lib.ConvDesc(ops._code(dtype), 1, 8, 8, ci, co, k, 1, 1, 1)
+        singles.append(ops.packed_weights(w, d, dtype, cache=False))
+        wf = torch.full((lib.fva_conv_packed_elems(C.byref(d), 0),), float('nan'), dtype=dtype, device=dev())
+        wd = torch.full((lib.fva_conv_packed_elems(C.byref(d), 1),), float('nan'), dtype=dtype, device=dev())
+        multis.append((wf, wd))
+        e = arr[i]
+        e.w, e.w_fwd, e.w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
+        e.Cout, e.Cin, e.ksize, e.dtype = co, ci, k, ops._code(dtype)
+        e.taps_fwd, e.taps_dgrad = wf.numel() // (co * ci), wd.numel() // (co * ci)
+        mx = max(mx, wf.numel(), wd.numel())
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    _lib.call('fva_conv_pack_weights_multi', ops._p(table), len(ws), mx, ops._stream())
+    for (sf, sd), (mf, md) in zip(singles, multis):
+        assert torch.equal(sf.float(), mf.float()) and torch.equal(sd.float(), md.float())
