@@ -6,7 +6,7 @@ The package mirrors the reference's Python surface for that path and nothing els
     fastvision_amd.detection.neck / .head / .models        (detection/{neck,head,models})
     fastvision_amd.detection.tools                         (IOU.py, BOX.py, GRID.py)
     fastvision_amd.loss                                    (yolov3_loss.py, iou_loss.py, classification_loss.py)
-    fastvision_amd.utils.Fit                               (utils/fit.py step contract)
+    fastvision_amd.utils.Fit, .utils.sheduler, .utils.checkpoints   (utils/fit.py step contract; f-1 helpers)
     fastvision_amd.demos.yolov3_u.{models,utils,cfg}       (demos/yolov3_u: YoloV3, ComputeLoss, Fit/_Train)
 
 plus ``FusedAdam`` and ``parallel`` (one process per GPU, RCCL gradient all-reduce).  All device arithmetic

@@ -1,1 +1,2 @@
-from .fit import *  # noqa: F401,F403
+from .checkpoints import *  # noqa: F401,F403
+from .fit import *          # noqa: F401,F403

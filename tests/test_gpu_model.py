@@ -373,3 +373,35 @@ def test_data_parallel_two_ranks_one_gpu():
     for k in g0:
         err = ((g0[k] - acc[k]).abs().max() / acc[k].abs().max().clamp_min(1e-12)).item()
         assert err < 1e-4, f'{k}: {err}'
+
+
+def test_config2_fp32_full_size_vs_oracle():
+    """BASELINE config 2 at full size: YOLOv3 8x3x416x416 fp32 (grids 13/26/52), one train step vs the CPU oracle on
+    the same seeded batch: heads and loss within 1e-3, per-tensor gradient norms within 2e-3, matcher indices exact."""
+    import fastvision_amd
+    from oracle import losses as ol, train as otrain
+    images, tg = synthetic_batch(8, 416)
+    torch.set_num_threads(max(1, min(16, len(__import__('os').sched_getaffinity(0)))))
+    ref, ref_crit = otrain.make_library(20220504)
+    ref_pred = ref(images)
+    ref_loss = ref_crit(ref_pred, tg)
+    ref_loss.backward()
+    with fastvision_amd.compute_dtype(torch.float32):
+        net, crit = lib_model(), lib_loss()
+        pred = net(images.to(DEV))
+        assert [tuple(p.shape) for p in pred] == [(8, 3, 13, 13, 85), (8, 3, 26, 26, 85), (8, 3, 52, 52, 85)]
+        loss = crit(pred, tg.to(DEV))
+        loss.backward()
+        locs, cats, _, _ = crit.build_target(pred, tg.to(DEV))
+    for h, r in zip(pred, ref_pred):
+        err = ((h.detach().cpu() - r.detach()).abs().max() / r.detach().abs().max()).item()
+        assert err < 1e-3, f'head {err}'
+    assert abs(loss.item() - ref_loss.item()) / ref_loss.item() < 1e-3
+    rlocs, rcats, _, _ = ol.build_target([p.shape for p in ref_pred], tg, ref.anchors_per_level, ref.backbone_strides_per_level)
+    for l in range(3):
+        assert torch.equal(locs[l][0].cpu(), rlocs[l][0]) and torch.equal(locs[l][1].cpu(), rlocs[l][1])
+        assert torch.equal(locs[l][2].cpu(), rlocs[l][2]) and torch.equal(cats[l].cpu(), rcats[l])
+    gn = np.array([[p.grad.norm().item(), r.grad.norm().item()] for (_, p), (_, r) in zip(net.named_parameters(), ref.named_parameters())])
+    rel = np.abs(gn[:, 0] - gn[:, 1]) / np.maximum(gn[:, 1], 1e-12)
+    print('cfg2 grad-norm rel dev: median', np.median(rel), 'max', rel.max())
+    assert rel.max() < 2e-3

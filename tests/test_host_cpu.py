@@ -111,3 +111,50 @@ def test_halo_view_detection():
     assert ops.halo_info(dense, torch.float32)[1] == 0
     assert ops.halo_info(torch.zeros(2, 8, 5, 6), torch.float32) is None      # plain NCHW is foreign
     assert ops.halo_info(view, torch.bfloat16) is None
+
+
+def test_lr_schedules_match_reference_values():
+    """utils/sheduler.py mirror vs values captured from the reference's own functions (tests/golden/sched.npz)."""
+    import numpy as np
+    from fastvision_amd.utils import sheduler as S
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'sched.npz'))
+
+    def curve(make, steps=12):
+        p = [torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD(p, lr=1.0)
+        sch = make(opt)
+        lrs = []
+        for _ in range(steps):
+            lrs.append(opt.param_groups[0]['lr'])
+            opt.step()
+            sch.step()
+        return np.array(lrs)
+
+    def wc(o):
+        for g in o.param_groups:
+            g['lr'] = 0.01
+        return S.WarmupCosineLR(o, milestones=[8, 14], min_ratio=0.1, cycle_decay=0.5, warmup_iters=4, warmup_factor=0.1)
+    np.testing.assert_allclose(curve(lambda o: S.CosineLR(o, 10, 0.01, 0.0001)), gold['cosine'], rtol=1e-12)
+    np.testing.assert_allclose(curve(lambda o: S.LinearLR(o, 10, 0.01, 0.0001)), gold['linear'], rtol=1e-12)
+    np.testing.assert_allclose(curve(lambda o: S.ExponentialLR(o, 10, 0.01, 0.0001)), gold['exp'], rtol=1e-12)
+    np.testing.assert_allclose(curve(wc, 20), gold['warmcos'], rtol=1e-12)
+    with pytest.raises(ValueError):
+        S.WarmupCosineLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0), milestones=[5, 3])
+
+
+def test_checkpoint_helpers_roundtrip(tmp_path):
+    from fastvision_amd.classfication.models.darknet53 import ConvBlock3x3
+    from fastvision_amd.utils import LoadFromParrel, LoadStatedict, SaveModel, SqueezeModel
+    torch.manual_seed(1)
+    a, b, c = ConvBlock3x3(32, 64), ConvBlock3x3(32, 64), ConvBlock3x3(32, 64)
+    path = str(tmp_path / 'last.pth')
+    SaveModel({'model': a, 'optimizer': {}}, path, weights_only=True)
+    blob = torch.load(path)
+    assert set(blob) == {'model', 'optimizer', 'date'} and list(blob['model']) == list(a.state_dict())
+    LoadStatedict(b, path, 'cpu')
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+    torch.save({'module.' + k: v for k, v in a.state_dict().items()}, path)        # a DataParallel checkpoint
+    LoadFromParrel(c, path, 'cpu')
+    assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())
+    SqueezeModel(c, ['bn'], False)
+    assert not c.bn.weight.requires_grad and c.conv.weight.requires_grad
