@@ -210,14 +210,37 @@ class _Saved:
 # concurrently with the same layer's dgrad, so the two fill each other's partially occupied last rounds.
 import os as _os
 _side_streams = {}
-OVERLAP_WGRAD = _os.environ.get('FVA_WGRAD_STREAM', '0') == '1'     # measured: 807 vs 823 img/s with it on -> off by default
+# FVA_WGRAD_STREAM: 0 = wgrad on the launch stream (default); 1 = side stream, joined right after the layer's dgrad
+# (measured 807 vs 823 img/s: off); 2 = low-priority side stream, joined once at the end of the backward pass
+WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '0'))
+OVERLAP_WGRAD = WGRAD_MODE == 1
+_pending_join = {}
 
 
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        st = _side_streams[device] = torch.cuda.Stream(device=device, priority=0)
     return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every wgrad still running on the side stream (end of backward / optimizer)."""
+    for dev, st in list(_side_streams.items()):
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
+    _pending_join.clear()
+
+
+def _defer_join(device):
+    if not _pending_join.get(device):
+        _pending_join[device] = True
+        main = torch.cuda.current_stream(device)
+
+        def _cb():
+            main.wait_stream(_side_stream(device))
+            _pending_join[device] = False
+        torch.autograd.Variable._execution_engine.queue_callback(_cb)
 
 
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
@@ -279,7 +302,16 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     overlap = OVERLAP_WGRAD and need_dx
-    if overlap:
+    if WGRAD_MODE == 2:
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+        for t in (dw, dy, s.keep if isinstance(getattr(s, 'keep', None), torch.Tensor) else s.x):
+            t.record_stream(side)                      # their memory must outlive the lagging wgrad
+        _defer_join(dev)
+    elif overlap:
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)                           # dY (and everything before it) is ready
         with torch.cuda.stream(side):
