@@ -224,23 +224,32 @@ def _side_stream(device):
     return st
 
 
+_inflight = {}      # device -> tensors a lagging wgrad still reads / writes (kept alive until the join)
+_side_ws = {}       # device -> one workspace shared by all side-stream wgrads (they run in order on that stream)
+
+
 def join_side_stream(device=None):
     """Make the current stream wait for every wgrad still running on the side stream (end of backward / optimizer)."""
     for dev, st in list(_side_streams.items()):
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(st)
-    _pending_join.clear()
+            _inflight.pop(dev, None)
+            _pending_join[dev] = False
 
 
 def _defer_join(device):
     if not _pending_join.get(device):
         _pending_join[device] = True
-        main = torch.cuda.current_stream(device)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_side_stream(device))
 
-        def _cb():
-            main.wait_stream(_side_stream(device))
-            _pending_join[device] = False
-        torch.autograd.Variable._execution_engine.queue_callback(_cb)
+
+def _side_workspace(device, nbytes, side):
+    ws = _side_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            ws.record_stream(side)                     # an in-flight wgrad may still use the old buffer
+        ws = _side_ws[device] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    return ws
 
 
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
@@ -303,13 +312,12 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     overlap = OVERLAP_WGRAD and need_dx
     if WGRAD_MODE == 2:
-        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
-        for t in (dw, dy, s.keep if isinstance(getattr(s, 'keep', None), torch.Tensor) else s.x):
-            t.record_stream(side)                      # their memory must outlive the lagging wgrad
+        side = _side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))          # dY is ready
+        ws = _side_workspace(dev, ws_bytes, side)
+        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes,
+                  C.c_void_p(side.cuda_stream))
+        _inflight.setdefault(dev, []).append((dw, dy, getattr(s, 'keep', None), s.x))   # outlive the lagging wgrad
         _defer_join(dev)
     elif overlap:
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
