@@ -286,6 +286,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         s = _Saved()
         s.d, s.x, s.x_ptr, s.y, s.scale, s.shift, s.mean, s.rstd, s.wd = d, x, x_ptr, y, scale, shift, mean, rstd, wd
         s.gamma, s.dtype, s.OH, s.OW, s.M, s.wshape = gamma, dtype, OH, OW, M, tuple(weight.shape)
+        s.weight = weight
         s.training = training
     return z, s
 
@@ -311,13 +312,21 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     overlap = OVERLAP_WGRAD and need_dx
-    if WGRAD_MODE == 2:
+    w_param = getattr(s, 'weight', None)
+    lag_ok = (WGRAD_MODE == 2 and w_param is not None and w_param.grad is None
+              and not getattr(w_param, '_post_accumulate_grad_hooks', None))
+    if lag_ok:
+        # The weight gradient may lag behind the critical path: nobody reads it before the end of backward.  That is
+        # only true if autograd will simply adopt the tensor (no existing .grad to add to -> no kernel on the main
+        # stream) and no post-accumulate hook (DP reducer) looks at it; otherwise take the in-order path below.
         side = _side_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))          # dY is ready
         ws = _side_workspace(dev, ws_bytes, side)
         _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes,
                   C.c_void_p(side.cuda_stream))
-        _inflight.setdefault(dev, []).append((dw, dy, getattr(s, 'keep', None), s.x))   # outlive the lagging wgrad
+        # dY and x must outlive the lagging kernel.  dw is NOT held here: an extra reference would make autograd's
+        # AccumulateGrad clone it (on the main stream, too early) instead of adopting it.
+        _inflight.setdefault(dev, []).append((dy, getattr(s, 'keep', None), s.x))
         _defer_join(dev)
     elif overlap:
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
