@@ -121,10 +121,6 @@ def main():
     images, targets = synthetic_batch(args.batch, args.size, rank=rank)     # per-rank shard of the global batch (weak scaling)
     images, targets = images.to(dev), targets.to(dev)
 
-    hi = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('FVA_WGRAD_STREAM') == '2' else None
-    if hi is not None:
-        torch.cuda.set_stream(hi)          # the critical path runs on a high-priority stream; wgrads fill its tails
-
     def step():
         pred = net(images)
         opt.zero_grad()

@@ -210,17 +210,30 @@ class _Saved:
 # concurrently with the same layer's dgrad, so the two fill each other's partially occupied last rounds.
 import os as _os
 _side_streams = {}
-# FVA_WGRAD_STREAM: 0 = wgrad on the launch stream (default); 1 = side stream, joined right after the layer's dgrad
-# (measured 807 vs 823 img/s: off); 2 = low-priority side stream, joined once at the end of the backward pass
-WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '0'))
+# FVA_WGRAD_STREAM: 0 = wgrad on the launch stream; 1 = side stream, joined right after the layer's dgrad (measured
+# 807 vs 823 img/s: worse); 2 (default) = LOW-priority side stream, joined once at the end of the backward pass
+# (measured 855 vs 841 img/s)
+WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '2'))
 OVERLAP_WGRAD = WGRAD_MODE == 1
 _pending_join = {}
 
 
 def _side_stream(device):
+    """A LOW-priority stream (HIP priority 1; torch's own streams are 0 or -1): its kernels are dispatched only when
+    the caller's stream leaves workgroup slots free, i.e. in the partially filled last rounds of the critical path."""
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device, priority=0)
+        try:
+            hip = C.CDLL('libamdhip64.so')
+            with torch.cuda.device(device):
+                torch.cuda.current_stream()            # make sure the context exists
+                h = C.c_void_p()
+                if hip.hipStreamCreateWithPriority(C.byref(h), 1, 1) != 0 or not h.value:   # hipStreamNonBlocking, least prio
+                    raise OSError('hipStreamCreateWithPriority failed')
+                st = torch.cuda.ExternalStream(h.value, device=device)
+        except (OSError, AttributeError):
+            st = torch.cuda.Stream(device=device, priority=0)
+        _side_streams[device] = st
     return st
 
 
