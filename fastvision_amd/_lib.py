@@ -100,15 +100,24 @@ def load():
 tracer = None   # set by fastvision_amd.profiler.KernelTimer: callable(name, args) -> context manager or None
 
 
+_fns = {}
+
+
 def call(name, *args):
     """Call a status-returning entry point; raise RuntimeError(fva_last_error()) on failure."""
-    lib = load()
-    span = tracer(name, args) if tracer is not None else None
-    if span is not None:
-        with span:
-            rc = getattr(lib, name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    lib = _lib
+    if tracer is not None:
+        span = tracer(name, args)
+        if span is not None:
+            with span:
+                rc = fn(*args)
+        else:
+            rc = fn(*args)
     else:
-        rc = getattr(lib, name)(*args)
+        rc = fn(*args)
     if name not in UNCHECKED and rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib.fva_last_error().decode()}')
     return rc
