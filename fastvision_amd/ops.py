@@ -211,10 +211,11 @@ class _Saved:
 # concurrently with the same layer's dgrad, so the two fill each other's partially occupied last rounds.
 import os as _os
 _side_streams = {}
-# FVA_WGRAD_STREAM: 0 = wgrad on the launch stream; 1 = side stream, joined right after the layer's dgrad (measured
-# 807 vs 823 img/s: worse); 2 (default) = LOW-priority side stream, joined once at the end of the backward pass
-# (measured 855 vs 841 img/s)
-WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '2'))
+# FVA_WGRAD_STREAM: 0 (default) = wgrad on the launch stream; 1 = side stream, joined right after the layer's dgrad
+# (measured 807 vs 823 img/s: worse); 2 = LOW-priority side stream, joined once at the end of the backward pass
+# (measured 846-856 vs 837-841 img/s: +1-2 %, but +8 ms host time per step and overlapping kernels blur the
+# per-kernel timings the roofline is read from, so it stays opt-in)
+WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '0'))
 OVERLAP_WGRAD = WGRAD_MODE == 1
 _pending_join = {}
 

@@ -1,4 +1,4 @@
-"""Live per-kernel timing with HIP events on the stream the kernels are launched on (torch's current stream).
+"""Live per-kernel timing with HIP events recorded on the stream each call is launched on (its `stream` argument).
 
     with KernelTimer() as kt:
         ... training steps ...
@@ -15,15 +15,27 @@ CONV_CALLS = {'fva_conv_fwd': 'conv_fwd', 'fva_conv_dgrad': 'conv_dgrad', 'fva_c
               'fva_head_fwd': 'conv_fwd'}
 
 
+_streams = {}
+
+
+def _stream_of(arg):
+    """torch handle for the raw hipStream_t an entry point was given (its last argument)."""
+    raw = getattr(arg, 'value', arg) or 0
+    st = _streams.get(raw)
+    if st is None:
+        st = _streams[raw] = torch.cuda.ExternalStream(raw) if raw else torch.cuda.default_stream()
+    return st
+
+
 class _Span:
-    def __init__(self, rec):
-        self.rec = rec
+    def __init__(self, rec, stream):
+        self.rec, self.stream = rec, stream
 
     def __enter__(self):
-        self.rec[1].record()
+        self.rec[1].record(self.stream)
 
     def __exit__(self, *a):
-        self.rec[2].record()
+        self.rec[2].record(self.stream)
 
 
 class KernelTimer:
@@ -40,7 +52,7 @@ class KernelTimer:
         rec = (cls, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flop,
                (d.Cin, d.Cout, d.ksize, d.stride, oh))
         self.records.append(rec)
-        return _Span(rec)
+        return _Span(rec, _stream_of(args[-1]))
 
     def __enter__(self):
         self.prev = _lib.tracer
