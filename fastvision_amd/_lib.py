@@ -28,6 +28,15 @@ class PackEntry(C.Structure):
                [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype')]
 
 
+class Letterbox(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('resize_ratio', 'pad_left', 'pad_top', 'ori_w', 'ori_h', 'min_wh')]
+
+
+class NmsParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('box_mode', 'score_mode', 'rethreshold', 'max_det', 'max_nms')] + \
+               [(n, C.c_float) for n in ('conf_thres', 'iou_thres', 'class_gap')]
+
+
 class MatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
 
@@ -73,10 +82,15 @@ PROTOTYPES = {
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),
     'fva_iou_batch': (_I, [_I, _I, _I, _P, _P, _P, _L, _L, _F, _P]),
     'fva_adam_step': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
+    'fva_yolo_decode': (_I, [_H, _I, _I, C.POINTER(Letterbox), _P, _L, _P]),
+    'fva_nms_candidates_workspace': (_L, [_I, _I]),
+    'fva_nms_candidates': (_I, [_P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P]),
+    'fva_nms_select_workspace': (_L, [_I, _I]),
+    'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
 UNCHECKED = {'fva_last_error', 'fva_version', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_bn_bwd_blocks', 'fva_yolov3_loss_workspace',
-             'fva_demo_loss_workspace'}
+             'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 
 _lib = None
 

@@ -1,1 +1,3 @@
 from .lossv3 import ComputeLoss  # noqa: F401
+from .nms import non_max_suppression, non_max_suppression_batch  # noqa: F401
+from .box import grid, xywh2xyxy  # noqa: F401

@@ -1,12 +1,13 @@
 """YOLOv3 assembly -- API mirror of the reference's detection/models/yolov3.py (Yolov3, yolov3).
 
 ``forward(images, val=False)``: train mode returns the raw head list (yolov3.py:54); eval / ``val=True`` also
-returns decoded boxes [B, sum 3*g*g, 5+C] (yolov3.py:35-53).  The decode is the validation-side "next" row of
-the scope table and runs as plain torch ops on the head tensors; its missing ``offset`` helper is restated as
-the [H,W,(x,y)] cell grid.
+returns decoded boxes [B, sum 3*g*g, 5+C] (yolov3.py:35-53), produced for all three levels by one HIP kernel
+(``fva_yolo_decode``); the reference's missing ``offset`` helper is the [H,W,(x,y)] cell grid.
 """
 import torch
 import torch.nn as nn
+
+from ...detect_ops import yolo_decode
 
 __all__ = ['Yolov3', 'yolov3']
 
@@ -21,6 +22,7 @@ class Yolov3(nn.Module):
         for n in num_anchors_per_level:
             self.anchors_per_level.append(anchors[start:start + n].view(n, 1, 1, 2))
             start += n
+        self._anchor_lists = [[(float(a[0]), float(a[1])) for a in lvl.view(-1, 2)] for lvl in self.anchors_per_level]
         self.num_classes = num_classes
         self.backbone = backbone(in_channels=in_channels, including_top=False)
         self.backbone_strides_per_level = self.backbone.backbone_strides_per_level()
@@ -33,17 +35,7 @@ class Yolov3(nn.Module):
         head_out = self.head(self.neck(self.backbone(images)))
         if self.training and not val:
             return head_out
-        results = []
-        for i, out in enumerate(head_out):
-            bs, _, height, width, _ = out.size()
-            ys = torch.arange(height, device=out.device).view(height, 1).expand(height, width)
-            xs = torch.arange(width, device=out.device).view(1, width).expand(height, width)
-            cell = torch.stack([xs, ys], dim=2).to(out).expand_as(out[..., 0:2])
-            xy = (out[..., 0:2].sigmoid() + cell) * self.backbone_strides_per_level[i]
-            wh = torch.exp(out[..., 2:4]) * self.anchors_per_level[i].expand_as(out[..., 2:4]).to(out)
-            dec = torch.cat((xy, wh, out[..., 4:].sigmoid()), -1)
-            results.append(dec.reshape(bs, -1, self.num_classes + 5))
-        return head_out, torch.cat(results, 1)
+        return head_out, yolo_decode(list(head_out), self._anchor_lists, self.backbone_strides_per_level, variant=0)
 
 
 def yolov3(backbone=None, neck=None, head=None, anchors=None, num_anchors_per_level=None, in_channels=3, num_classes=80,

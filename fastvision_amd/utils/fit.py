@@ -1,11 +1,15 @@
 """Training loop -- API mirror of the reference's utils/fit.py (class Fit): the CALLER of the accelerated path.
 
 ``_train`` keeps the reference's per-batch contract (fit.py:52-66): pred = model(images); optimizer.zero_grad();
-loss = self.loss(pred, labels); loss.backward(); optimizer.step(); scheduler.step() per epoch.  Validation in the
-reference also runs NMS + mAP (fit.py:73-105: torchvision / metrics, the "next" rows f-2 of the scope table); here
-``_val`` reports the validation loss only.
+loss = self.loss(pred, labels); loss.backward(); optimizer.step(); scheduler.step() per epoch.  ``_val`` follows
+fit.py:73-105: eval-mode forward with decode, validation loss, NMS (conf 0.25, IoU 0.45, 300 detections) and
+CalculateMAP over IoU 0.5:0.95 -- decode and NMS run in the HIP kernels, one NMS pass per batch instead of one per image.
 """
+import numpy as np
 import torch
+
+from ..detection.tools import non_max_suppression_images, xywh2xyxy
+from ..metrics import CalculateMAP
 
 __all__ = ['Fit']
 
@@ -25,6 +29,7 @@ class Fit:
             self._train(epoch)
             if self.val_loader:
                 self._val()
+                self.model.train()
         if self.test_loader:
             self._test()
 
@@ -54,13 +59,28 @@ class Fit:
         return self.history[-1]
 
     def _val(self):
+        """Returns {'loss': [...per batch], 'map_each_iou', 'map_each_cls', 'map_each_cls_idx'}.  Like the reference
+        (fit.py:79) this iterates ``train_loader`` when no ``val_loader`` was given."""
+        loader = self.val_loader or self.train_loader
+        map_est = CalculateMAP(map_iou_values=np.linspace(0.5, 0.95, 10))
         self.model.eval()
-        out = []
+        losses = []
         with torch.no_grad():
-            for images, labels in self.val_loader:
+            for images, labels in loader:
                 images, labels = self._to_device(images, labels)
-                head_out, _ = self.model(images, val=True)
-                out.append(float(self.loss(head_out, labels)))
+                head_out, results = self.model(images, val=True)
+                losses.append(float(self.loss(head_out, labels)))
+                scale = torch.tensor([images.size(3), images.size(2), images.size(3), images.size(2)]).to(labels)
+                dets = non_max_suppression_images(results, conf_thres=0.25, iou_thres=0.45, max_det=300)
+                for img_idx, (conf, cls, xyxy) in enumerate(dets):
+                    predict = torch.cat([cls.float(), conf, xyxy], dim=1)
+                    target = labels[labels[:, 0] == img_idx, 1:].clone()
+                    target[:, 1:] = xywh2xyxy(target[:, 1:]) * scale
+                    map_est.process_one(predict, target)
+        out = {'loss': losses}
+        if map_est.seen_all_targets_cls and map_est.correct_all_images:
+            out['map_each_iou'], out['map_each_cls'], out['map_each_cls_idx'] = map_est.fetch()
+        self.last_val = out
         return out
 
     def _test(self):

@@ -207,6 +207,49 @@ int fva_iou_pairwise(int kind, int mode, int variant, const float* a, const floa
 int fva_iou_batch(int kind, int mode, int variant, const float* a, const float* b, float* out, int64_t N, int64_t M, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Validation side (scope row f-2): eval decode, candidate selection, non-maximum suppression.
+ * ---------------------------------------------------------------------------------------------- */
+/* Un-letterbox mapping of the demo's postProcess (demos/yolov3_u/inference.py:90-106). */
+typedef struct {
+    float resize_ratio, pad_left, pad_top; /* x_ori = (x - pad_left) / resize_ratio */
+    float ori_w, ori_h;                    /* clamp bounds of the original image */
+    float min_wh;                          /* boxes with w <= min_wh or h <= min_wh are dropped (5 in the reference) */
+} fva_letterbox;
+/* Decode the head tensors of all levels into out [B][rows_per_image][K] fp32 (level after level).
+ * variant 0 -- Yolov3.forward eval branch (detection/models/yolov3.py:35-53): rows of a level ordered (a, y, x);
+ *   xy = (sigmoid(t) + cell) * stride, wh = exp(t) * anchor (PIXEL anchors), everything else sigmoid.
+ * variant 1 -- postProcess (demos/yolov3_u/inference.py:58-88): rows ordered (y, x, a);
+ *   xy = (2 sigmoid(t) - 0.5 + cell) * stride, wh = (2 sigmoid(t))^2 * anchor * stride (FEATURE anchors).
+ *   With lb != NULL rows additionally go through :90-106: un-letterbox, clamp, xywh -> clamped xyxy in columns 0..3;
+ *   rows the reference drops (w or h <= min_wh) keep their place with objectness -1. */
+int fva_yolo_decode(const fva_head_level* levels, int32_t nlevels, int32_t variant, const fva_letterbox* lb,
+                    float* out, int64_t rows_per_image, void* stream);
+
+typedef struct {
+    int32_t box_mode;    /* 0: rows carry xywh (converted with x -/+ w/2), 1: rows carry xyxy */
+    int32_t score_mode;  /* 0: score = max_c(cls_c * obj) (NMS.py:13-16, nms.py:76-82); 1: score = obj (nms.py:24-36) */
+    int32_t rethreshold; /* 1: also drop candidates with max_c(cls_c * obj) <= conf_thres (nms.py:84) */
+    int32_t max_det;     /* detections kept per image */
+    int32_t max_nms;     /* > 0: only the max_nms best candidates enter NMS (nms.py:40-42: 30000) */
+    float conf_thres, iou_thres;
+    float class_gap;     /* 0: class-agnostic (NMS.py); 4096: boxes shifted by category * gap (nms.py:45-46) */
+} fva_nms_params;
+/* Stage 1: rows with objectness > conf_thres become candidates, in row order (what boolean-mask indexing gives).
+ * pred [B][R][K] fp32; counts [B] i32; cand: opaque buffer of fva_nms_candidates_workspace(B, R) bytes. */
+int64_t fva_nms_candidates_workspace(int32_t B, int32_t R);
+int fva_nms_candidates(const float* pred, int32_t B, int32_t R, int32_t K, const fva_nms_params* p, void* cand,
+                       int64_t cand_bytes, int32_t* counts, void* stream);
+/* Stage 2: torchvision.ops.nms on every image's candidates (greedy, highest score first, suppress when
+ * inter / (area_a + area_b - inter) > iou_thres; score ties broken by candidate order).  nmax >= max(counts)
+ * (the caller reads counts back: the reference's boolean indexing synchronises at the same point).
+ * out [B][max_det][6] = x1, y1, x2, y2, score, category; out_rows [B][max_det] = source row in pred;
+ * keep_counts [B]. */
+int64_t fva_nms_select_workspace(int32_t B, int32_t nmax);
+int fva_nms_select(const void* cand, const int32_t* counts, int32_t B, int32_t R, int32_t nmax, const fva_nms_params* p,
+                   void* workspace, int64_t workspace_bytes, float* out, int32_t* out_rows, int32_t* keep_counts,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (demos/yolov3_u/train.py:68), multi-tensor.
  * ptrs: device array [4][n] of {param, grad, exp_avg, exp_avg_sq} fp32 pointers; sizes: device int64[n].
  * step is the 1-based step count; lr/betas/eps/weight_decay as torch (L2-in-gradient decay).

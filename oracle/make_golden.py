@@ -9,7 +9,8 @@ integer ``clamp_`` bound).  No reference source is copied: the fixtures are inpu
     python oracle/make_golden.py lib      # library surface  (fastvision.*)
     python oracle/make_golden.py demo     # demo surface     (demos/yolov3_u)   -- separate process: its
                                           # top-level ``utils``/``models`` names clash with nothing else then
-    python oracle/make_golden.py all      # both, as two child processes
+    python oracle/make_golden.py eval_lib / eval_demo   # validation side (decode, NMS wrappers, mAP): scope row f-2
+    python oracle/make_golden.py all      # everything, one child process per surface
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 """
@@ -394,6 +395,176 @@ def gen_demo():
     print('demo fixtures:', len(out), 'arrays')
 
 
+# ====================================================================================== validation side (scope row f-2)
+def _install_nms():
+    """torchvision is absent, so the reference's NMS wrappers run with the oracle's restatement of torchvision.ops.nms
+    standing in for it (oracle/detect.py: the suppression core itself stays 'parity unpinned')."""
+    from oracle.detect import nms
+    tv, ops = sys.modules['torchvision'], sys.modules['torchvision.ops']
+    tv.ops = ops
+    ops.nms = nms
+
+
+def _numpy_aliases():
+    """fifth harness shim: metrics/map.py spells float64 / int64 as np.float / np.long (numpy < 1.24)."""
+    np.float = float
+    np.long = np.int64
+    if not hasattr(np, 'trapz'):
+        np.trapz = np.trapezoid
+
+
+def synth_predictions(gen, R, n_obj, size, conf_low=0.02):
+    """[R,85] decoded-looking rows: n_obj clusters of overlapping boxes with high objectness over a low-conf background,
+    a few exact duplicates (score ties) included."""
+    import torch
+    p = torch.rand(R, 85, generator=gen)
+    p[:, 0:2] = torch.rand(R, 2, generator=gen) * size
+    p[:, 2:4] = 8 + torch.rand(R, 2, generator=gen) * size / 3
+    p[:, 4] = torch.rand(R, generator=gen) * conf_low
+    per = max(1, R // (4 * max(n_obj, 1)))
+    for o in range(n_obj):
+        c = torch.rand(4, generator=gen)
+        base = torch.tensor([c[0] * size, c[1] * size, 20 + c[2] * size / 2, 20 + c[3] * size / 2])
+        idx = torch.randperm(R, generator=gen)[:per]
+        p[idx, 0:4] = base + torch.randn(per, 4, generator=gen) * 3
+        p[idx, 4] = 0.3 + 0.7 * torch.rand(per, generator=gen)
+        cls = int(torch.randint(0, 80, (1,), generator=gen))
+        p[idx, 5 + cls] = 0.9 + 0.1 * torch.rand(per, generator=gen)
+        if per >= 3:
+            p[idx[1]] = p[idx[0]]              # exact duplicate: tie in score, IoU 1
+    return p
+
+
+def gen_eval_lib():
+    import torch
+    T = boot_lib()
+    _install_nms()
+    _numpy_aliases()
+    from fastvision.classfication.models.darknet53 import darknet53
+    from fastvision.detection.neck.yolov3neck import yolov3neck
+    from fastvision.detection.head.yolov3head import yolov3head
+    from fastvision.detection.models.yolov3 import yolov3
+    from fastvision.detection.tools.NMS import non_max_suppression
+    from fastvision.metrics.map import CalculateMAP
+    out = {}
+    # ---- E1: eval branch of Yolov3.forward (decode) on the whole model, S = 64 and 96 ---------------------
+    for case, (S, B, seed) in enumerate(((64, 2, 11), (96, 1, 12))):
+        torch.manual_seed(seed)
+        m = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(),
+                   num_anchors_per_level=[3, 3, 3], in_channels=3, num_classes=80, training=False)
+        m.eval()
+        g = torch.Generator().manual_seed(seed)
+        # give BatchNorm non-trivial running statistics, as a trained checkpoint has
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+        images = torch.rand(B, 3, S, S, generator=g)
+        with torch.no_grad():
+            head_out, results = m(images)
+        out[f'e1_{case}_cfg'] = np.array([S, B, seed])
+        out[f'e1_{case}_images'] = images.numpy()
+        for l in range(3):
+            out[f'e1_{case}_head{l}'] = head_out[l].numpy()
+        out[f'e1_{case}_results'] = results.numpy()
+    # ---- E2: non_max_suppression (NMS.py) around the restated nms --------------------------------------------
+    cases = [(2000, 6, 416, 0.25, 0.45, 300, 0.02), (500, 3, 416, 0.25, 0.45, 5, 0.02), (300, 0, 416, 0.25, 0.45, 300, 0.02),
+             (700, 4, 640, 0.001, 0.6, 300, 1.0), (64, 2, 64, 0.25, 0.45, 300, 0.02), (1, 1, 64, 0.0, 0.45, 300, 1.0)]
+    for case, (R, n_obj, size, ct, it, md, low) in enumerate(cases):
+        g = torch.Generator().manual_seed(500 + case)
+        pred = synth_predictions(g, R, n_obj, size, low)
+        sc, cat, box = non_max_suppression(pred.clone(), conf_thres=ct, iou_thres=it, max_det=md)
+        out[f'e2_{case}_cfg'] = np.array([ct, it, md], dtype=np.float64)
+        out[f'e2_{case}_pred'] = pred.numpy()
+        out[f'e2_{case}_scores'] = sc.numpy().reshape(-1)
+        out[f'e2_{case}_cats'] = cat.numpy().reshape(-1).astype(np.int64)
+        out[f'e2_{case}_boxes'] = box.numpy().reshape(-1, 4)
+    # ---- E3: CalculateMAP over a few synthetic images --------------------------------------------------------
+    est = CalculateMAP(map_iou_values=np.linspace(0.5, 0.95, 10))
+    g = torch.Generator().manual_seed(77)
+    n_img = 6
+    for i in range(n_img):
+        nt = [5, 0, 9, 3, 12, 1][i]
+        tcls = torch.randint(0, 4, (nt,), generator=g).float()
+        txy = torch.rand(nt, 2, generator=g) * 300
+        twh = 20 + torch.rand(nt, 2, generator=g) * 100
+        target = torch.cat([tcls.view(-1, 1), txy, txy + twh], dim=1)
+        keep = torch.rand(nt, generator=g) > 0.25                     # detected targets, jittered
+        pbox = target[keep, 1:] + torch.randn(int(keep.sum()), 4, generator=g) * 6
+        pcls = target[keep, 0].clone()
+        nf = [3, 2, 4, 0, 5, 0][i]                                    # false positives
+        fxy = torch.rand(nf, 2, generator=g) * 300
+        fbox = torch.cat([fxy, fxy + 30 + torch.rand(nf, 2, generator=g) * 60], dim=1)
+        fcls = torch.randint(0, 5, (nf,), generator=g).float()
+        box = torch.cat([pbox, fbox])
+        cls = torch.cat([pcls, fcls])
+        conf = torch.rand(box.size(0), generator=g)
+        if i == 2 and box.size(0) >= 2:
+            box[1] = box[0]
+            cls[1] = cls[0]                                           # duplicate detection of one target
+        pred = torch.cat([cls.view(-1, 1), conf.view(-1, 1), box], dim=1)
+        est.process_one(pred, target)
+        out[f'e3_{i}_pred'] = pred.numpy()
+        out[f'e3_{i}_target'] = target.numpy()
+    for i, c in enumerate(est.correct_all_images):
+        out[f'e3_correct{i}'] = c
+    out['e3_n'] = np.array([n_img, len(est.correct_all_images)])
+    map_iou, map_cls, cls_idx = est.fetch()
+    out['e3_map_each_iou'] = map_iou
+    out['e3_map_each_cls'] = map_cls
+    out['e3_cls_idx'] = np.array(cls_idx)
+    np.savez_compressed(os.path.join(GOLD, 'eval_lib.npz'), **out)
+    print('eval_lib fixtures:', len(out), 'arrays')
+
+
+def gen_eval_demo():
+    import torch
+    boot_demo()
+    for n in ('albumentations', 'albumentations.pytorch'):
+        sys.modules[n] = type(sys.modules['cv2'])(n)
+    _install_nms()
+    _numpy_aliases()
+    # inference.py is a script: it calls Inference() (GPU + COCO files) at import time.  Execute it as a module and keep
+    # what it had defined by then (postProcess is all that is used).
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('inference', os.path.join(REF, 'demos', 'yolov3_u', 'inference.py'))
+    INF = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(INF)
+    except (RuntimeError, AssertionError, FileNotFoundError):
+        pass
+    from utils.nms import non_max_suppression, non_max_suppression_batch
+    out = {}
+    strides = [32, 16, 8]
+    anchors = [a.view(-1, 2) for a in coco_anchors_feature()]
+    # ---- D1: postProcess (decode, un-letterbox, clamps, size filter, NMS) on raw head tensors -----------------
+    for case, (S, rr, pl, pt, ow, oh, ct) in enumerate(((64, 0.1, 0, 8, 640, 480, 0.3), (96, 0.2, 12, 0, 360, 480, 0.5))):
+        g = torch.Generator().manual_seed(900 + case)
+        layers = [torch.randn(1, 255, S // s, S // s, generator=g) * 1.5 for s in strides]
+        sc, cat, box = INF.postProcess([l.clone() for l in layers], strides, anchors, ct, 0.45, rr, pl, pt, ow, oh)
+        out[f'd1_{case}_cfg'] = np.array([S, rr, pl, pt, ow, oh, ct, 0.45], dtype=np.float64)
+        for l in range(3):
+            out[f'd1_{case}_layer{l}'] = layers[l].numpy()
+        out[f'd1_{case}_scores'] = sc.numpy().reshape(-1)
+        out[f'd1_{case}_cats'] = cat.numpy().reshape(-1)
+        out[f'd1_{case}_boxes'] = box.numpy().reshape(-1, 4)
+    # ---- D2: non_max_suppression (xyxy rows in) and non_max_suppression_batch (xywh rows in) -------------------
+    for case, (R, n_obj, ct, it, md) in enumerate(((1500, 5, 0.25, 0.45, 300), (400, 3, 0.25, 0.45, 4), (200, 0, 0.25, 0.45, 300))):
+        g = torch.Generator().manual_seed(950 + case)
+        pred = synth_predictions(g, R, n_obj, 416)
+        xyxy = pred.clone()
+        xyxy[:, 2:4] = xyxy[:, 0:2] + pred[:, 2:4]
+        res = non_max_suppression(xyxy.clone(), conf_thres=ct, iou_thres=it, max_det=md)
+        resb = non_max_suppression_batch([pred.clone(), pred.flip(0).clone()], conf_thres=ct, iou_thres=it, max_det=md)
+        out[f'd2_{case}_cfg'] = np.array([ct, it, md], dtype=np.float64)
+        out[f'd2_{case}_pred'] = pred.numpy()
+        out[f'd2_{case}_single'] = res.numpy().reshape(-1, 6)
+        out[f'd2_{case}_batch0'] = resb[0].numpy().reshape(-1, 6)
+        out[f'd2_{case}_batch1'] = resb[1].numpy().reshape(-1, 6)
+    np.savez_compressed(os.path.join(GOLD, 'eval_demo.npz'), **out)
+    print('eval_demo fixtures:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLD, exist_ok=True)
@@ -401,7 +572,11 @@ if __name__ == '__main__':
         gen_lib()
     elif which == 'demo':
         gen_demo()
+    elif which == 'eval_lib':
+        gen_eval_lib()
+    elif which == 'eval_demo':
+        gen_eval_demo()
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for s in ('lib', 'demo'):
+        for s in ('lib', 'demo', 'eval_lib', 'eval_demo'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s], env=env)
