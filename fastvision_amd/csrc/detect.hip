@@ -13,41 +13,44 @@ constexpr int MAX_LEVELS = 4;
 
 struct DecodeParams {
     fva_head_level lv[MAX_LEVELS];
-    int64_t row0[MAX_LEVELS + 1];
+    int row0[MAX_LEVELS + 1];
+    FastDiv div_k, div_w[MAX_LEVELS], div_a[MAX_LEVELS];
     int nlevels, variant, has_lb;
     fva_letterbox lb;
-    int64_t rows, total;  // rows per image, B * rows * K
+    int rows, per_image;  // rows per image, rows * K
     int K;
 };
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p, float* __restrict__ out) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= p.total) return;
-    const int k = (int)(i % p.K);
-    const int64_t br = i / p.K;
-    const int64_t r = br % p.rows;
-    const int b = (int)(br / p.rows);
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams kp, float* __restrict__ out) {
+    // the level table is indexed by a per-thread level and anchor: keep it in LDS (dynamic indexing of kernel
+    // arguments would go through scratch memory)
+    __shared__ DecodeParams p;
+    static_assert(sizeof(DecodeParams) % 4 == 0, "copied as dwords");
+    for (int q = threadIdx.x; q < (int)(sizeof(DecodeParams) / 4); q += 256) ((uint32_t*)&p)[q] = ((const uint32_t*)&kp)[q];
+    __syncthreads();
+    // one image per blockIdx.y; threads walk the elements in INPUT order (level, y, x, a, k): the head kernels write
+    // [B][H][W][A*K], so a wave reads whole 128-B lines; 32-bit index arithmetic with precomputed reciprocals
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.per_image) return;
+    const int b = blockIdx.y;
+    const int r = (int)fd_div((uint32_t)e, p.div_k);
+    const int k = e - r * p.K;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < MAX_LEVELS; ++q)
         if (q < p.nlevels && r >= p.row0[q]) l = q;
     const fva_head_level& lv = p.lv[l];
-    const int rr = (int)(r - p.row0[l]);
-    int a, y, x;
-    if (p.variant == 0) {  // rows (a, y, x)
-        a = rr / (lv.H * lv.W);
-        const int rem = rr - a * lv.H * lv.W;
-        y = rem / lv.W;
-        x = rem - y * lv.W;
-    } else {  // rows (y, x, a)
-        a = rr % lv.A;
-        const int c = rr / lv.A;
-        y = c / lv.W;
-        x = c - y * lv.W;
-    }
+    const int rr = r - p.row0[l];
+    const int c = (int)fd_div((uint32_t)rr, p.div_a[l]);
+    const int a = rr - c * lv.A;
+    const int y = (int)fd_div((uint32_t)c, p.div_w[l]);
+    const int x = c - y * lv.W;
+    // output row: (a, y, x) for the library variant, (y, x, a) for the demo
+    const int orow = p.row0[l] + (p.variant == 0 ? a * lv.H * lv.W + c : rr);
+    const int64_t i = ((int64_t)b * p.rows + orow) * p.K + k;
     const float* src = lv.data + b * lv.sb + a * lv.sa + y * lv.sy + x * lv.sx;
     // centre / size of axis 0 (x, w) or 1 (y, h) in input pixels
     auto centre = [&](int axis) {
@@ -323,11 +326,14 @@ extern "C" int fva_yolo_decode(const fva_head_level* levels, int32_t nlevels, in
         const fva_head_level& lv = levels[l];
         if (!lv.data || lv.A < 1 || lv.A > 8 || lv.H < 1 || lv.W < 1 || lv.B != levels[0].B || lv.K != levels[0].K || lv.K < 6)
             return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: bad level %d", l);
+        if (rows + (int64_t)lv.A * lv.H * lv.W >= (1ll << 24)) return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: too many rows per image");
         p.lv[l] = lv;
-        p.row0[l] = rows;
+        p.row0[l] = (int)rows;
+        p.div_w[l] = make_fastdiv(lv.W);
+        p.div_a[l] = make_fastdiv(lv.A);
         rows += (int64_t)lv.A * lv.H * lv.W;
     }
-    p.row0[nlevels] = rows;
+    p.row0[nlevels] = (int)rows;
     if (rows != rows_per_image) return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: rows_per_image %lld, levels hold %lld", (long long)rows_per_image, (long long)rows);
     p.nlevels = nlevels;
     p.variant = variant;
@@ -336,12 +342,12 @@ extern "C" int fva_yolo_decode(const fva_head_level* levels, int32_t nlevels, in
         if (!(lb->resize_ratio > 0.f)) return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: resize_ratio must be positive");
         p.lb = *lb;
     }
-    p.rows = rows;
+    p.rows = (int)rows;
     p.K = levels[0].K;
-    p.total = (int64_t)levels[0].B * rows * p.K;
-    if (p.total >= (1ll << 40)) return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: too large");
-    const int64_t blocks = (p.total + 255) / 256;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, out);
+    if (rows * p.K >= (1ll << 31) || levels[0].B > 65535) return fva_fail(FVA_ERR_ARG, "fva_yolo_decode: too large");
+    p.per_image = (int)(rows * p.K);
+    p.div_k = make_fastdiv(p.K);
+    hipLaunchKernelGGL(decode_kernel, dim3(cdiv(p.per_image, 256), levels[0].B), dim3(256), 0, (hipStream_t)stream, p, out);
     FVA_LAUNCH_CHECK("decode_kernel");
     return FVA_OK;
 }
