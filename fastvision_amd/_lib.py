@@ -25,7 +25,7 @@ class HeadLevel(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [('w', C.c_void_p), ('w_fwd', C.c_void_p), ('w_dgrad', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype')]
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype', 'dgrad_paired', 'reserved')]
 
 
 class Letterbox(C.Structure):

@@ -461,8 +461,15 @@ void finish_taps(IgemmParams& p, int ntaps, int dtype) {
     }
 }
 
+// destination of tap (ky, kx), input channel ci in the paired stride-2 dgrad layout [v][2*Cin][Cout] (see dgrad_paired)
+__device__ __forceinline__ int64_t paired_row(int t, int ci, int Cin) {
+    const int ky = t / 3, kx = t - ky * 3;
+    const int v = ky * 2 + (kx == 0 ? 1 : 0);
+    return (int64_t)v * 2 * Cin + (kx == 1 ? ci : Cin + ci);
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void* dgr, int Cout, int Cin, int kk,
-                                    int taps_f, int taps_d, int bf16) {
+                                    int taps_f, int taps_d, int bf16, int paired) {
     // one thread per (tap, co, ci) of the padded space max(taps_f, taps_d) x Cout x Cin
     const int64_t total = (int64_t)(taps_f > taps_d ? taps_f : taps_d) * Cout * Cin;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -474,7 +481,16 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* fwd, void
             const int64_t o = ((int64_t)t * Cout + co) * Cin + ci;
             if (bf16) ((bf16_t*)fwd)[o] = (bf16_t)v; else ((float*)fwd)[o] = v;
         }
-        if (dgr && t < taps_d) {
+        if (dgr && paired) {
+            if (t < kk) {
+                const int64_t o = paired_row(t, ci, Cin) * Cout + co;
+                if (bf16) ((bf16_t*)dgr)[o] = (bf16_t)v; else ((float*)dgr)[o] = v;
+                if (t % 3 == 0) {  // the x-even half of a dxo=1 tap is zero
+                    const int64_t z = (paired_row(t, ci, Cin) - Cin) * Cout + co;
+                    if (bf16) ((bf16_t*)dgr)[z] = (bf16_t)0.f; else ((float*)dgr)[z] = 0.f;
+                }
+            }
+        } else if (dgr && t < taps_d) {
             const int64_t o = ((int64_t)t * Cin + ci) * Cout + co;
             if (bf16) ((bf16_t*)dgr)[o] = (bf16_t)v; else ((float*)dgr)[o] = v;
         }
@@ -511,9 +527,19 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_
                 }
                 // dgrad layout [t][ci][co]: row = ci, lanes along co
                 if (e.w_dgrad && ci0 + r < e.Cin && co0 + l < e.Cout) {
-                    const int64_t o = ((int64_t)t * e.Cin + ci0 + r) * e.Cout + co0 + l;
                     const float v = tile[l][r * kk + t];
-                    if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                    if (e.dgrad_paired) {
+                        const int64_t row = paired_row(t, ci0 + r, e.Cin);
+                        const int64_t o = row * e.Cout + co0 + l;
+                        if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                        if (t % 3 == 0) {
+                            const int64_t z = (row - e.Cin) * e.Cout + co0 + l;
+                            if (bf) ((bf16_t*)e.w_dgrad)[z] = (bf16_t)0.f; else ((float*)e.w_dgrad)[z] = 0.f;
+                        }
+                    } else {
+                        const int64_t o = ((int64_t)t * e.Cin + ci0 + r) * e.Cout + co0 + l;
+                        if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                    }
                 }
             }
         }
@@ -523,11 +549,25 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_
     const int64_t cc = (int64_t)e.Cout * e.Cin;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cc; i += (int64_t)gridDim.x * blockDim.x) {
         if (e.w_fwd && e.taps_fwd > kk) { if (bf) ((bf16_t*)e.w_fwd)[kk * cc + i] = (bf16_t)0.f; else ((float*)e.w_fwd)[kk * cc + i] = 0.f; }
-        if (e.w_dgrad && e.taps_dgrad > kk) { if (bf) ((bf16_t*)e.w_dgrad)[kk * cc + i] = (bf16_t)0.f; else ((float*)e.w_dgrad)[kk * cc + i] = 0.f; }
+        if (e.w_dgrad && !e.dgrad_paired && e.taps_dgrad > kk) { if (bf) ((bf16_t*)e.w_dgrad)[kk * cc + i] = (bf16_t)0.f; else ((float*)e.w_dgrad)[kk * cc + i] = 0.f; }
     }
 }
 
+// Stride-2 dgrad of thin layers: the two output x-parities of a row are produced together as N' = 2*Cin columns (the
+// pixel pair (2j, 2j+1) is contiguous in NHWC), from "virtual taps" v = ky*2 + dxo whose [2*Cin][Cout] matrices hold
+// kx=1 | kx=2 for dxo=0 and zeros | kx=0 for dxo=1.  2 launches instead of 4, full-line stores, 4/3 of the MACs.
+inline int pair_max_cin() {
+    static int v = [] {
+        const char* e = getenv("FVA_DGRAD_PAIR_MAX");
+        return e ? atoi(e) : 64;
+    }();
+    return v;
+}
+inline bool dgrad_paired(int ksize, int stride, int Cin) { return ksize == 3 && stride == 2 && Cin <= pair_max_cin(); }
+
 int packed_taps(const fva_conv_desc* d, int for_dgrad) {
+    if (for_dgrad && dgrad_paired(d->ksize, d->stride, d->Cin)) return 12;   // 6 virtual taps x 2 parities
+
     const int kk = d->ksize * d->ksize;
     const int C = for_dgrad ? d->Cout : d->Cin;
     return (halfrow_mode(d->dtype, C) && (kk & 1)) ? kk + 1 : kk;
@@ -546,11 +586,12 @@ int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, v
     int rc = check_desc(d, "fva_conv_pack_weights");
     if (rc) return rc;
     if (!w) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights: null weights");
-    const int tf = packed_taps(d, 0), td = packed_taps(d, 1);
+    const int paired = dgrad_paired(d->ksize, d->stride, d->Cin) ? 1 : 0;
+    const int tf = packed_taps(d, 0), td = paired ? d->ksize * d->ksize : packed_taps(d, 1);
     const int64_t total = (int64_t)(tf > td ? tf : td) * d->Cout * d->Cin;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_dgrad, d->Cout,
-                       d->Cin, d->ksize * d->ksize, tf, td, d->dtype == FVA_BF16 ? 1 : 0);
+                       d->Cin, d->ksize * d->ksize, tf, td, d->dtype == FVA_BF16 ? 1 : 0, paired);
     FVA_LAUNCH_CHECK("pack_weights_kernel");
     return FVA_OK;
 }
@@ -671,8 +712,42 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
         p.out_dense = 1;
         return launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
     }
-    // stride 2, 3x3: four output-parity classes, each with its own tap subset (no wasted MACs)
     const int JH = d->H / 2, JW = d->W / 2;
+    if (dgrad_paired(k, s, d->Cin)) {
+        // thin layers: both x-parities of an output row per launch (see dgrad_paired) -- 2 launches, N' = 2*Cin
+        p.M = d->B * JH * JW;
+        p.N = 2 * d->Cin;
+        p.OW = JW;
+        p.OHW = JH * JW;
+        p.div_ow = make_fastdiv(p.OW);
+        p.div_ohw = make_fastdiv(p.OHW);
+        p.y0 = p.x0 = 0;
+        p.out_dense = 0;
+        p.out_img = d->H * d->W;
+        p.out_row = d->W;
+        p.osy = p.osx = 2;
+        p.oox = 0;
+        for (int py = 0; py < 2; ++py) {
+            int nt = 0;
+            const int nky = py == 0 ? 1 : 2;
+            const int kys[2] = {py == 0 ? 1 : 0, 2};
+            const int yos[2] = {py == 0 ? d->dy_pad : d->dy_pad + 1, d->dy_pad};
+            for (int a = 0; a < nky; ++a)
+                for (int dxo = 0; dxo < 2; ++dxo) {
+                    p.tap_pix[nt] = yos[a] * p.in_row + d->dy_pad + dxo;
+                    p.tap_w[nt] = kys[a] * 2 + dxo;
+                    ++nt;
+                }
+            p.tap_w[nt] = 0;
+            finish_taps(p, nt, d->dtype);
+            if (p.halfrow) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: paired stride-2 path needs Cout >= 64");
+            p.ooy = py;
+            rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        return FVA_OK;
+    }
+    // stride 2, 3x3: four output-parity classes, each with its own tap subset (no wasted MACs)
     p.M = d->B * JH * JW;
     p.OW = JW;
     p.OHW = JH * JW;

@@ -146,7 +146,7 @@ class _PackRegistry:
 
     def add(self, weight, desc, wf, wd):
         import weakref
-        self.entries[id(weight)] = (weakref.ref(weight), (desc.Cout, desc.Cin, desc.ksize, desc.dtype), wf, wd)
+        self.entries[id(weight)] = (weakref.ref(weight), (desc.Cout, desc.Cin, desc.ksize, desc.dtype, desc.stride), wf, wd)
         self.table = None
 
     def repack_all(self, device):
@@ -161,11 +161,12 @@ class _PackRegistry:
         if self.table is None or self.table[0] != len(live) or self.table[3] != device:
             arr = (_lib.PackEntry * len(live))()
             mx = 0
-            for i, (w, (co, ci, k, dt), wf, wd) in enumerate(live):
+            for i, (w, (co, ci, k, dt, st), wf, wd) in enumerate(live):
                 e = arr[i]
                 e.w, e.w_fwd, e.w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
                 e.Cout, e.Cin, e.ksize, e.dtype = co, ci, k, dt
                 e.taps_fwd, e.taps_dgrad = wf.numel() // (co * ci), wd.numel() // (co * ci)
+                e.dgrad_paired = 1 if (st == 2 and e.taps_dgrad == 12) else 0
                 mx = max(mx, wf.numel(), wd.numel())
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
             self.table = (len(live), raw, mx, device, [w.data_ptr() for w, *_ in live])
@@ -173,7 +174,7 @@ class _PackRegistry:
             self.table = None
             return self.repack_all(device)
         _lib.call('fva_conv_pack_weights_multi', _p(self.table[1]), self.table[0], self.table[2], _stream())
-        for w, (co, ci, k, dt), wf, wd in live:
+        for w, (co, ci, k, dt, st), wf, wd in live:
             w._fva_packed = ((w._version, w.data_ptr(), dt), wf, wd)
 
 

@@ -69,6 +69,9 @@ typedef struct {
     void* w_fwd;          /* [taps_fwd][Cout][Cin]   (may be NULL) */
     void* w_dgrad;        /* [taps_dgrad][Cin][Cout] (may be NULL) */
     int32_t Cout, Cin, ksize, taps_fwd, taps_dgrad, dtype;
+    int32_t dgrad_paired; /* 1 when taps_dgrad == 12: the paired stride-2 layout [6][2*Cin][Cout] thin layers use
+                           * (fva_conv_packed_elems() of a stride-2 descriptor tells; see conv_igemm.hip dgrad_paired) */
+    int32_t reserved;
 } fva_pack_entry;
 int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t max_elems, void* stream);
 
