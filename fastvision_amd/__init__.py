@@ -6,6 +6,7 @@ The package mirrors the reference's Python surface for that path and nothing els
     fastvision_amd.detection.neck / .head / .models        (detection/{neck,head,models})
     fastvision_amd.detection.tools                         (IOU.py, BOX.py, GRID.py, NMS.py)
     fastvision_amd.metrics                                 (map.py: CalculateMAP)
+    fastvision_amd.datasets                                (detection_dataloader.py: decode on host, the rest on device)
     fastvision_amd.loss                                    (yolov3_loss.py, iou_loss.py, classification_loss.py)
     fastvision_amd.utils.Fit, .utils.sheduler, .utils.checkpoints   (utils/fit.py step contract; f-1 helpers)
     fastvision_amd.demos.yolov3_u.{models,utils,cfg}       (demos/yolov3_u: YoloV3, ComputeLoss, Fit/_Train, nms, postProcess)

@@ -37,6 +37,11 @@ class NmsParams(C.Structure):
                [(n, C.c_float) for n in ('conf_thres', 'iou_thres', 'class_gap')]
 
 
+class PasteJob(C.Structure):
+    _fields_ = [('src_offset', C.c_int64)] + [(n, C.c_int32) for n in ('src_h', 'src_w', 'dst_h', 'dst_w', 'top', 'left', 'flip_h', 'flip_v', 'src_pitch', 'reserved')] + \
+               [('scale_x', C.c_double), ('scale_y', C.c_double)]
+
+
 class MatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
 
@@ -82,6 +87,8 @@ PROTOTYPES = {
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),
     'fva_iou_batch': (_I, [_I, _I, _I, _P, _P, _P, _L, _L, _F, _P]),
     'fva_adam_step': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
+    'fva_paste_resize_normalize': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'fva_paste_resize_u8': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'fva_yolo_decode': (_I, [_H, _I, _I, C.POINTER(Letterbox), _P, _L, _P]),
     'fva_nms_candidates_workspace': (_L, [_I, _I]),
     'fva_nms_candidates': (_I, [_P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P]),

@@ -1,0 +1,114 @@
+"""API mirror of the image path of the reference's demos/yolov3_u/data_gen.py, on the GPU.
+
+The reference resizes, flips, pads and tiles (Mosaic01) decoded images one by one with cv2 on the CPU
+(data_gen.py:42-131,171-216) and divides by 255 after ToTensor (:352-360).  ``DeviceAugmenter`` does the same steps for a
+whole batch with two kernel launches (``fva_paste_resize_u8`` for the per-image ResizeByMax + flips,
+``fva_paste_resize_normalize`` for Padding or Mosaic01 + ``/ 255``); the box arithmetic stays in numpy float32 on the
+host, written as the reference writes it.  Not reproduced: HistEqualize (CLAHE), HueSaturationValue, the albumentations
+blur / ChannelShuffle transforms and image decoding -- they are not needed by the validation path and are optional,
+probability-0.5 extras of the training path.
+"""
+import numpy as np
+import torch
+
+from ...pipeline_ops import PasteJob, canvas_sources, pack_images, paste_batch, paste_batch_u8, value_table
+from .utils.box import xyxy2xywhn
+
+__all__ = ['DeviceAugmenter', 'resize_by_max_shape']
+
+
+def resize_by_max_shape(h, w, max_size):
+    """(resize_ratio, resized_h, resized_w) of ResizeByMax (data_gen.py:50-55)"""
+    ratio = max_size / max(h, w)
+    return ratio, int(h * ratio), int(w * ratio)
+
+
+def _hflip_boxes(xyxy, width):
+    """HorizontalFlip's label half (data_gen.py:104-106): via xywh, centre mirrored"""
+    xywh = np.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]], axis=1)
+    xywh[:, 0] = width - xywh[:, 0]
+    return np.stack([xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2], axis=1)
+
+
+def _vflip_boxes(xyxy, height):
+    xywh = np.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]], axis=1)
+    xywh[:, 1] = height - xywh[:, 1]
+    return np.stack([xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2], axis=1)
+
+
+class DeviceAugmenter:
+    def __init__(self, input_size, device='cuda', fill_value=128):
+        self.input_size, self.device, self.fill_value = int(input_size), device, int(fill_value)
+        self.table = value_table(single=True)
+
+    def _labels(self, xyxy, cat):
+        """xyxy (pixels of the input canvas) -> [n,6] rows 0, class, xc, yc, w, h (data_gen.py:362-367)"""
+        xywhn = xyxy2xywhn(xyxy, self.input_size, self.input_size)
+        rows = np.zeros([xywhn.shape[0], 6], dtype=np.float32)
+        rows[:, 1] = cat
+        rows[:, 2:] = xywhn
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def _collate(self, images, labels):
+        for i, l in enumerate(labels):
+            l[:, 0] = i
+        return images, torch.cat(labels, 0).to(self.device, non_blocking=True)
+
+    def val_batch(self, samples):
+        """samples: list of (rgb uint8 [h,w,3], xyxy float32 [n,4], category [n]).  ResizeByMax(input_size) -> Padding(128) ->
+        / 255 (data_gen.py:42-92,356-360) for the whole batch in one launch."""
+        S = self.input_size
+        buf, offsets, shapes = pack_images([s[0] for s in samples])
+        jobs, labels = [], []
+        for i, ((h, w), (_, xyxy, cat)) in enumerate(zip(shapes, samples)):
+            ratio, rh, rw = resize_by_max_shape(h, w, S)
+            top, left = int((S - rh) // 2), int((S - rw) // 2)
+            jobs.append(PasteJob(i, i, rh, rw, top, left))
+            lab = np.asarray(xyxy, dtype=np.float32) * ratio
+            lab[:, [1, 3]] = lab[:, [1, 3]] + top
+            lab[:, [0, 2]] = lab[:, [0, 2]] + left
+            labels.append(self._labels(lab, cat))
+        images = paste_batch(buf, offsets, shapes, jobs, len(samples), S, S, self.fill_value, self.table, self.device)
+        return self._collate(images, labels)
+
+    def train_batch(self, groups):
+        """groups: per output image a list of FOUR (rgb, xyxy, category, hflip, vflip) -- the sample and its three random
+        companions (data_gen.py:338-345).  Pass 1 (uint8): ResizeByMax(input_size) + flips of all 4*B images; pass 2:
+        Mosaic01 (each tile resized again to input_size // 2 on its longer side, the four meet at the centre) + / 255."""
+        S = self.input_size
+        flat = [t for g in groups for t in g]
+        buf, offsets, shapes = pack_images([t[0] for t in flat])
+        jobs1, mid_shapes, mid_boxes = [], [], []
+        for i, ((h, w), (_, xyxy, cat, hf, vf)) in enumerate(zip(shapes, flat)):
+            ratio, rh, rw = resize_by_max_shape(h, w, S)
+            jobs1.append(PasteJob(i, i, rh, rw, 0, 0, hf, vf))
+            lab = np.asarray(xyxy, dtype=np.float32) * ratio
+            if hf:
+                lab = _hflip_boxes(lab, rw)
+            if vf:
+                lab = _vflip_boxes(lab, rh)
+            mid_shapes.append((rh, rw))
+            mid_boxes.append(lab)
+        mid = paste_batch_u8(buf, offsets, shapes, jobs1, len(flat), S, S, self.fill_value, self.device)
+        m_off, m_shapes, m_pitch = canvas_sources(len(flat), S, S, mid_shapes)
+        jobs2, labels = [], []
+        cx = cy = S // 2
+        for b, g in enumerate(groups):
+            boxes, cats = [], []
+            for idx in range(4):
+                i = b * 4 + idx
+                rh, rw = mid_shapes[i]
+                ratio, th, tw = resize_by_max_shape(rh, rw, S // 2)
+                x0 = cx - tw if idx in (0, 2) else cx
+                y0 = cy - th if idx in (0, 1) else cy
+                jobs2.append(PasteJob(i, b, th, tw, y0, x0))
+                lab = mid_boxes[i] * ratio
+                lab[:, [0, 2]] = lab[:, [0, 2]] + x0
+                lab[:, [1, 3]] = lab[:, [1, 3]] + y0
+                boxes.append(lab)
+                cats.append(np.asarray(g[idx][2]))
+            xyxy = np.clip(np.concatenate(boxes, axis=0), 0, S - 1)
+            labels.append(self._labels(xyxy, np.concatenate(cats, axis=0).reshape(-1)))
+        images = paste_batch(mid.view(-1), m_off, m_shapes, jobs2, len(groups), S, S, self.fill_value, self.table, self.device,
+                             pitches=m_pitch)
+        return self._collate(images, labels)

@@ -253,6 +253,34 @@ int fva_nms_select(const void* cand, const int32_t* counts, int32_t B, int32_t R
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input side (scope row f-3): decoded uint8 RGB (HWC) images -> the [B][3][H][W] fp32 input batch in one launch.
+ * A "paste job" resizes one source image with OpenCV's 8-bit INTER_LINEAR arithmetic (an exact 2x decimation is
+ * area-averaged, as cv2.resize does) to dst_w x dst_h, optionally mirrors it, and places it at (left, top) of canvas
+ * `b`; pixels no job covers take `fill`.  Every byte then goes through lut[channel][value] (the caller tabulates
+ * x/255 or (x/255 - mean)/std exactly as the reference computes it).  Replaces cv2.resize + Padding + np.fliplr/flipud
+ * + Normalization + transpose + stack (datasets/detection_dataloader.py:44-103, datasets/common/padding.py,
+ * datasets/common/augmentation.py:298-376) and ResizeByMax/Padding/flips/Mosaic01 (demos/yolov3_u/data_gen.py).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t src_offset;      /* byte offset of this image's [src_h][src_w][3] pixels in `src` */
+    int32_t src_h, src_w;
+    int32_t dst_h, dst_w;    /* size after the resize */
+    int32_t top, left;       /* where the resized image lands on its canvas */
+    int32_t flip_h, flip_v;  /* mirror the resized image (cv2.flip 1 / 0) */
+    int32_t src_pitch;       /* bytes between source rows; 0 = src_w * 3 (a sub-image of a wider canvas otherwise) */
+    int32_t reserved;
+    double scale_x, scale_y; /* 1.0 / ((double)dst / src), as cv2.resize derives them */
+} fva_paste_job;
+/* jobs: DEVICE array; job_start: DEVICE int32[B+1], canvas b owns jobs job_start[b] .. job_start[b+1]-1, pasted in
+ * that order (later jobs overwrite earlier ones); lut: DEVICE float[3][256]; out: [B][3][H][W] fp32. */
+int fva_paste_resize_normalize(const uint8_t* src, const fva_paste_job* jobs, const int32_t* job_start, int32_t B,
+                               int32_t H, int32_t W, int32_t fill, const float* lut, float* out, void* stream);
+/* The same placement without the value table: out [B][H][W][3] uint8 (an intermediate image that a later call resizes
+ * again -- the demo resizes every image to input_size before Mosaic01 resizes it to input_size/2). */
+int fva_paste_resize_u8(const uint8_t* src, const fva_paste_job* jobs, const int32_t* job_start, int32_t B, int32_t H,
+                        int32_t W, int32_t fill, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (demos/yolov3_u/train.py:68), multi-tensor.
  * ptrs: device array [4][n] of {param, grad, exp_avg, exp_avg_sq} fp32 pointers; sizes: device int64[n].
  * step is the 1-based step count; lr/betas/eps/weight_decay as torch (L2-in-gradient decay).

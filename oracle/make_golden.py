@@ -10,6 +10,7 @@ integer ``clamp_`` bound).  No reference source is copied: the fixtures are inpu
     python oracle/make_golden.py demo     # demo surface     (demos/yolov3_u)   -- separate process: its
                                           # top-level ``utils``/``models`` names clash with nothing else then
     python oracle/make_golden.py eval_lib / eval_demo   # validation side (decode, NMS wrappers, mAP): scope row f-2
+    python oracle/make_golden.py pipeline / pipeline_demo   # input side (resize, pad, flips, normalise, labels): row f-3
     python oracle/make_golden.py all      # everything, one child process per surface
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
@@ -565,6 +566,130 @@ def gen_eval_demo():
     print('eval_demo fixtures:', len(out), 'arrays')
 
 
+# ====================================================================================== input side (scope row f-3)
+def _install_cv2():
+    """cv2 is absent: the reference's dataset classes run with the oracle's restatements of the four OpenCV calls they make
+    (oracle/pipeline.py: the resampler itself stays 'parity unpinned'); imread serves synthetic images from memory."""
+    from oracle import pipeline as P
+    cv2 = sys.modules['cv2']
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT, cv2.COLOR_BGR2RGB = 1, 0, 4
+    cv2.resize = lambda img, dsize, interpolation=1: P.resize_linear_u8(img, dsize)
+    cv2.copyMakeBorder = lambda img, t, b, l, r, kind, value=0: P.copy_make_border_constant(img, t, b, l, r, value)
+    cv2.flip = P.flip
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    cv2._images = {}
+    cv2.imread = lambda path: cv2._images[path].copy()
+    return cv2
+
+
+def synth_image(gen, h, w):
+    """uint8 HWC image with structure at several scales (so that resampling errors show)"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w, 3), dtype=np.float32)
+    for c in range(3):
+        f = gen.uniform(0.01, 0.3, size=4)
+        img[..., c] = 127 + 60 * np.sin(xx * f[0] + yy * f[1] + c) + 50 * np.cos(xx * f[2] - yy * f[3])
+    img += gen.normal(0, 12, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_boxes(gen, n, h, w):
+    x0, y0 = gen.uniform(0, w * 0.7, n), gen.uniform(0, h * 0.7, n)
+    bw, bh = gen.uniform(4, w * 0.3, n), gen.uniform(4, h * 0.3, n)
+    cls = gen.integers(0, 80, n)
+    return [(float(c), float(a), float(b), float(a + d), float(b + e)) for c, a, b, d, e in zip(cls, x0, y0, bw, bh)]
+
+
+# (source h, w, input size, boxes): small on purpose (fixtures stay small); 256x256 -> 128 is the exact-2x (area) case,
+# 128x128 -> 128 the identity, the last one a full-size 640 sample kept as a strided subsample + checksums
+PIPE_CASES = [(120, 160, 128, 5), (111, 167, 128, 3), (160, 107, 128, 7), (256, 256, 128, 2), (100, 37, 64, 1), (128, 128, 128, 4),
+              (75, 248, 96, 6), (97, 211, 64, 2), (480, 640, 640, 5)]
+
+
+def gen_pipeline():
+    boot_lib()
+    cv2 = _install_cv2()
+    sys.modules['fastvision.detection.plot'] = types.ModuleType('fastvision.detection.plot')      # plotting helper (cv2 drawing)
+    sys.modules['fastvision.detection.plot'].draw_box_label = lambda *a, **k: None
+    from fastvision.datasets.detection_dataloader import BaseDataset
+    from fastvision.datasets.common.padding import Padding
+    gen = np.random.default_rng(2024)
+    out = {}
+    samples = []
+    for i, (h, w, S, n) in enumerate(PIPE_CASES):
+        rgb = synth_image(gen, h, w)
+        cv2._images[f'img{i}'] = np.ascontiguousarray(rgb[:, :, ::-1])          # imread hands out BGR
+        ann = synth_boxes(gen, n, h, w)
+        out[f'p_{i}_rgb'] = rgb
+        out[f'p_{i}_ann'] = np.array(ann, dtype=np.float64)
+        samples.append((f'img{i}', ann, S))
+    out['p_cases'] = np.array(PIPE_CASES)
+    # ---- L1: BaseDataset.__getitem__ under every flip combination ------------------------------------------
+    for i, (path, ann, S) in enumerate(samples):
+        ds = BaseDataset([(path, ann)], S, max_det=200)
+        for hf in (0, 1):
+            for vf in (0, 1):
+                ds.augmentation.augmentations[0].p = 2.0 if hf else -1.0      # random.random() <= p
+                ds.augmentation.augmentations[1].p = 2.0 if vf else -1.0
+                img, lab = ds[0]
+                if S <= 128:
+                    out[f'l1_{i}_{hf}{vf}_img'] = img.numpy()
+                else:
+                    out[f'l1_{i}_{hf}{vf}_img_sub'] = img.numpy()[:, ::7, ::5]
+                    out[f'l1_{i}_{hf}{vf}_img_sums'] = np.array([img.double().sum().item(), (img.double() ** 2).sum().item()])
+                out[f'l1_{i}_{hf}{vf}_lab'] = lab.numpy()
+    # ---- L2: collate of a mixed batch (same input size) ------------------------------------------------------
+    ds = BaseDataset([(p, a) for p, a, S in samples if S == 128], 128, max_det=200)
+    for a in ds.augmentation.augmentations[:2]:
+        a.p = -1.0
+    imgs, labs = BaseDataset.collate_fn([ds[j] for j in range(len(ds))])
+    out['l2_index'] = np.array([i for i, (_, _, S) in enumerate(samples) if S == 128])
+    out['l2_labels'] = labs.numpy()
+    out['l2_image_sums'] = imgs.double().sum(dim=(1, 2, 3)).numpy()
+    # ---- L3: Padding offsets over a range of sizes (its round(x -/+ 0.1) rule) --------------------------------
+    rows = []
+    for rh in range(1, 41):
+        for rw in (1, 2, 3, 17, 40):
+            _, pos = Padding(np.zeros((rh, rw, 3), np.uint8), input_size=(40, 40), color=(114, 114, 114), align='center')
+            rows.append((rh, rw) + tuple(pos))
+    out['l3_padding'] = np.array(rows)
+    np.savez_compressed(os.path.join(GOLD, 'pipeline.npz'), **out)
+    print('pipeline fixtures:', len(out), 'arrays')
+
+
+def gen_pipeline_demo():
+    boot_demo()
+    for n in ('albumentations', 'albumentations.pytorch'):
+        sys.modules[n] = type(sys.modules['cv2'])(n)
+    _install_cv2()
+    import data_gen as DG
+    gen = np.random.default_rng(777)
+    out = {}
+    imgs = []
+    for i, (h, w) in enumerate(((120, 160), (125, 83), (53, 80), (160, 160))):
+        rgb = synth_image(gen, h, w)
+        ann = np.array(synth_boxes(gen, 3 + i, h, w), dtype=np.float32)
+        out[f'q_{i}_rgb'] = rgb
+        out[f'q_{i}_ann'] = ann
+        imgs.append((rgb, ann[:, 1:].copy(), ann[:, 0].copy()))
+    # ---- D1: ResizeByMax, flips, Padding (validation path) -----------------------------------------------------
+    for i, (rgb, xyxy, cat) in enumerate(imgs):
+        im, lb = DG.ResizeByMax(rgb.copy(), xyxy.copy(), 96)
+        out[f'd1_{i}_resized'], out[f'd1_{i}_resized_lab'] = im, lb
+        imh, lbh = DG.HorizontalFlip(im.copy(), lb.copy())
+        imv, lbv = DG.VerticalFlip(imh.copy(), lbh.copy())
+        out[f'd1_{i}_hv'], out[f'd1_{i}_hv_lab'] = imv, lbv
+        pim, plb = DG.Padding(imv.copy(), lbv.copy(), 96, fill_value=128)
+        out[f'd1_{i}_padded'], out[f'd1_{i}_padded_lab'] = pim, plb
+    # ---- D2: Mosaic01 -------------------------------------------------------------------------------------------------
+    for case, S in enumerate((96, 160)):
+        pre = [DG.ResizeByMax(a.copy(), b.copy(), S) + (c.copy(),) for a, b, c in imgs]      # preprocess_image_label does this first
+        m, xyxy, cat = DG.Mosaic01(pre, S, fill_value=128)
+        out[f'd2_{case}_image'], out[f'd2_{case}_xyxy'], out[f'd2_{case}_cat'] = m, xyxy, cat
+    np.savez_compressed(os.path.join(GOLD, 'pipeline_demo.npz'), **out)
+    print('pipeline_demo fixtures:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLD, exist_ok=True)
@@ -576,7 +701,11 @@ if __name__ == '__main__':
         gen_eval_lib()
     elif which == 'eval_demo':
         gen_eval_demo()
+    elif which == 'pipeline':
+        gen_pipeline()
+    elif which == 'pipeline_demo':
+        gen_pipeline_demo()
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for s in ('lib', 'demo', 'eval_lib', 'eval_demo'):
+        for s in ('lib', 'demo', 'eval_lib', 'eval_demo', 'pipeline', 'pipeline_demo'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s], env=env)
