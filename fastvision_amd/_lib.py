@@ -69,6 +69,7 @@ PROTOTYPES = {
     'fva_head_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_head_bwd_prepare': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'fva_bn_finalize': (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    'fva_bn_partial_rows': (_I, [_I]),
     'fva_bn_eval_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'fva_bn_silu_apply': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'fva_bn_silu_bwd_reduce': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
@@ -96,7 +97,7 @@ PROTOTYPES = {
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
 UNCHECKED = {'fva_last_error', 'fva_version', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
-             'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_bn_bwd_blocks', 'fva_yolov3_loss_workspace',
+             'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 
 _lib = None

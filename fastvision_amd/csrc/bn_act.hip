@@ -37,16 +37,47 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
     s1 = (double)a0 + (double)a1;
     s2 = (double)b0 + (double)b1;
 }
+// Layers with many row blocks (the 640^2 / 320^2 maps: up to 51200 partial rows for 2-4 channel groups) first fold
+// chunks of PRE_ROWS rows in parallel into doubles kept in the tail of the same table (rows nblocks .. of
+// fva_bn_partial_rows()): tail[(r * 2 + which) * C + c].  Fixed order everywhere: deterministic.
+constexpr int PRE_ROWS = 256, PRE_MIN = 1024;
+__global__ __launch_bounds__(1024) void bn_prereduce_kernel(const float* __restrict__ part, int nblocks, int C, double* __restrict__ tail) {
+    __shared__ double red[2][FIN_G][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const int r0 = blockIdx.y * PRE_ROWS;
+    const int n = nblocks - r0 < PRE_ROWS ? nblocks - r0 : PRE_ROWS;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) reduce_partials(part + (int64_t)r0 * 2 * C, n, C, c, ry, s1, s2);
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry < 2 && c < C) {
+        double s = 0.0;
+        for (int k = 0; k < FIN_G; ++k) s += red[ry][k][cx];
+        tail[((int64_t)blockIdx.y * 2 + ry) * C + c] = s;
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* running_mean, float* running_var, int64_t* nbt,
                                                            float momentum, float eps, float* save_mean, float* save_rstd,
-                                                           float* scale, float* shift) {
+                                                           float* scale, float* shift, const double* __restrict__ pre, int pre_rows) {
     __shared__ double red[2][FIN_G][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) reduce_partials(part, nblocks, C, c, ry, s1, s2);
+    if (c < C) {
+        if (pre_rows > 0) {  // pre-reduced doubles
+            for (int r = ry; r < pre_rows; r += FIN_G) {
+                s1 += pre[((int64_t)r * 2 + 0) * C + c];
+                s2 += pre[((int64_t)r * 2 + 1) * C + c];
+            }
+        } else {
+            reduce_partials(part, nblocks, C, c, ry, s1, s2);
+        }
+    }
     red[0][ry][cx] = s1;
     red[1][ry][cx] = s2;
     __syncthreads();
@@ -388,16 +419,32 @@ inline int stream_grid(int64_t items) {
 
 extern "C" {
 
-int fva_bn_finalize(const float* part, int32_t nblocks, int64_t count, int32_t C, const float* gamma, const float* beta,
+int fva_bn_finalize(float* part, int32_t nblocks, int64_t count, int32_t C, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                     float* save_mean, float* save_rstd, float* scale, float* shift, void* stream) {
     if (!part || !gamma || !beta || !save_mean || !save_rstd || !scale || !shift || nblocks <= 0 || count <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, part, nblocks, (double)count,
+    const double* pre = nullptr;
+    int pre_rows = 0;
+    if (nblocks >= PRE_MIN) {
+        pre_rows = cdiv(nblocks, PRE_ROWS);
+        // the table was allocated with fva_bn_partial_rows(nblocks) rows: doubles live behind the nblocks float rows
+        double* tail = (double*)(part + ((int64_t)nblocks * 2 * C + 1) / 2 * 2);
+        pre = tail;
+        hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(C, 16), pre_rows), dim3(1024), 0, (hipStream_t)stream, (const float*)part, nblocks,
+                           C, tail);
+        FVA_LAUNCH_CHECK("bn_prereduce_kernel");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, nblocks, (double)count,
                        C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, save_mean, save_rstd,
-                       scale, shift);
+                       scale, shift, pre, pre_rows);
     FVA_LAUNCH_CHECK("bn_finalize_kernel");
     return FVA_OK;
+}
+
+int32_t fva_bn_partial_rows(int32_t nblocks) {
+    if (nblocks < PRE_MIN) return nblocks;
+    return nblocks + 2 * cdiv(nblocks, PRE_ROWS) + 1;   // pre-reduced doubles (2 floats each) + alignment slack
 }
 
 int fva_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,

@@ -286,7 +286,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     mean = rstd = None
     if training:
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
-        stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
+        stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
@@ -420,7 +420,7 @@ class StemFn(torch.autograd.Function):
         mean = rstd = None
         if training:
             nblk = lib.fva_stem_stat_blocks(B, H, W)
-            stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
+            stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
             _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), _p(stats), B, Cin, H, W, Cout, _stream())
             mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
             _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),

@@ -116,8 +116,11 @@ int fva_head_bwd_prepare(int dtype, const float* dhead, const float* grad_scale,
  * ---------------------------------------------------------------------------------------------- */
 /* Reduce conv partial stats -> batch mean / biased var; update running stats (momentum, unbiased var) and
  * num_batches_tracked += 1 (both optional: NULL skips); emit save_mean, save_rstd and the fused
- * scale = gamma*rstd, shift = beta - mean*scale. */
-int fva_bn_finalize(const float* stats_partial, int32_t nblocks, int64_t count, int32_t C,
+ * scale = gamma*rstd, shift = beta - mean*scale.
+ * stats_partial must hold fva_bn_partial_rows(nblocks) rows of [2][C] floats: the conv kernels fill the first
+ * nblocks rows; tables of >= 1024 rows are first folded in parallel into the extra rows (scratch). */
+int32_t fva_bn_partial_rows(int32_t nblocks);
+int fva_bn_finalize(float* stats_partial, int32_t nblocks, int64_t count, int32_t C,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_rstd,
                     float* scale, float* shift, void* stream);

@@ -248,3 +248,33 @@ def test_multi_tensor_weight_pack_matches_single(key):
     _lib.call('fva_conv_pack_weights_multi', ops._p(table), len(ws), mx, ops._stream())
     for (sf, sd), (mf, md) in zip(singles, multis):
         assert torch.equal(sf.float(), mf.float()) and torch.equal(sd.float(), md.float())
+
+
+@pytest.mark.parametrize('nblocks', [7, 1023, 1024, 3001, 51200])
+def test_bn_finalize_large_tables(nblocks):
+    """partial tables of >= 1024 rows go through the parallel pre-reduce (rows behind nblocks are its scratch)"""
+    from fastvision_amd import _lib, ops
+    lib = _lib.load()
+    Cc = 32
+    g = torch.Generator().manual_seed(nblocks)
+    rows = lib.fva_bn_partial_rows(nblocks)
+    assert rows >= nblocks
+    part = torch.full((rows, 2, Cc), float('nan'), device=dev())
+    vals = torch.rand(nblocks, 2, Cc, generator=g) * 50
+    vals[:, 1] += 3000                                        # sum of squares dominates the squared mean
+    part[:nblocks] = vals.to(dev())
+    count = nblocks * 256
+    gamma, beta = torch.rand(Cc, generator=g).to(dev()) + 0.5, torch.randn(Cc, generator=g).to(dev())
+    rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+    mean, rstd, scale, shift = (torch.empty(Cc, device=dev()) for _ in range(4))
+    _lib.call('fva_bn_finalize', ops._p(part), nblocks, count, Cc, ops._p(gamma), ops._p(beta), ops._p(rm), ops._p(rv), ops._p(nbt),
+              0.1, 1e-5, ops._p(mean), ops._p(rstd), ops._p(scale), ops._p(shift), ops._stream())
+    s = vals.double().sum(0)
+    m = s[0] / count
+    var = s[1] / count - m * m
+    assert torch.allclose(mean.cpu().double(), m, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(rstd.cpu().double(), 1 / torch.sqrt(var + 1e-5), rtol=2e-5)
+    assert torch.allclose(rm.cpu().double(), 0.1 * m, rtol=2e-6, atol=1e-7)
+    assert int(nbt) == 1
+    assert torch.equal(part[:nblocks].cpu(), vals)            # the inputs themselves are not touched
