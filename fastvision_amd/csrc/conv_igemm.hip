@@ -386,6 +386,287 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     return FVA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 along m x 4 along n, 128x64 each), the "8-phase" schedule of the CDNA GEMM playbook
+// (cdna_hip_programming.md section 5): one block per CU, two LDS buffers of four 16-KiB half-tiles (A rows / B rows of the
+// first and second half of every wave's sub-tile), a k-tile consumed in four phases of 16 MFMAs (one 64x32 quadrant of
+// the wave's accumulator each), one half-tile of LDS-DMA issued per phase, counted vmcnt once per k-tile, and the two
+// wave groups (wr = 0 / 1) running half a phase apart so that one group's MFMAs cover the other group's LDS reads.
+//
+// Hazards (phase p of k-tile t = q_p(t); "stage X(t)" = LDS-DMA of half-tile X of k-tile t into buffer t & 1):
+//   q0: read B-h0, A-h0 | stage A-h1(t+1)      q1: read B-h1 | stage B-h0(t+2)
+//   q2: read A-h1       | stage A-h0(t+2)      q3: no reads  | stage B-h1(t+2), then vmcnt(6) (everything up to
+//                                                              A-h1(t+1) has landed => k-tile t+1 complete)
+//   RAW: the wait precedes q3's first barrier, the first read of k-tile t+1 is in q0(t+1), behind q3's second barrier,
+//        which the other group only reaches after its own wait.
+//   WAR: every phase retires its LDS reads (lgkmcnt(0)) before its first barrier; a half-tile is re-staged at the earliest
+//        one phase after its last read, so the re-staging wave has passed a barrier that every reader reached after
+//        retiring (B-h0: read q0, staged q1; A-h0: q0 -> q2; B-h1: q1 -> q3; A-h1: q2 -> q0 of the next k-tile).
+template <int EPI>
+__global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p) {
+    using T = bf16_t;
+    constexpr int BM = 256, BN = 256, NT = 512, BK = 64;
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;   // bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 2, wc = w & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int mblk = logical / p.nblocks, nblk = logical - mblk * p.nblocks;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+
+    // ---- per-lane source rows of the LDS-DMA pieces: piece (i, w) of a half-tile = its rows (i*8 + w)*8 .. +8 -------
+    const T* a_ptr[2][2];
+    const T* b_ptr[2][2];
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ (((w & 1) << 2) + (lane >> 4));   // source chunk landing at LDS slot (lane & 7)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rh = (i * 8 + w) * 8 + lrow;                   // row inside the half-tile, 0..127
+            int m = m0 + (rh >> 6) * 128 + h * 64 + (rh & 63);
+            m = m < p.M ? m : p.M - 1;
+            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+            const uint32_t oy = fd_div(rem, p.div_ow);
+            const uint32_t ox = rem - oy * (uint32_t)p.OW;
+            const int64_t pix = (int64_t)b * p.in_img + (int64_t)(oy * p.sy + p.y0) * p.in_row + (ox * p.sx + p.x0);
+            a_ptr[h][i] = (const T*)p.in + pix * p.C + chunk * 8;
+            int n = n0 + (rh >> 5) * 64 + h * 32 + (rh & 31);
+            n = n < p.N ? n : p.N - 1;
+            b_ptr[h][i] = (const T*)p.wt + (int64_t)n * p.C + chunk * 8;
+        }
+
+    int* ktab = (int*)(smem + 2 * BUF);
+    for (int e = tid; e < p.ktiles; e += NT) {
+        const int t = e / p.kt_per_tap, kk = e - t * p.kt_per_tap;
+        int tp = 0, tw = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_TAPS; ++i)
+            if (i == t) { tp = p.tap_pix[i]; tw = p.tap_w[i]; }
+        ktab[2 * e] = tp * p.C + kk * BK;
+        ktab[2 * e + 1] = tw * p.N * p.C + kk * BK;
+    }
+    __syncthreads();
+
+    // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1
+    auto stage = [&](int kind, int kt) {
+        char* dst = smem + (kt & 1) * BUF + kind * HALF + w * 1024;
+        const int off = ktab[2 * kt + (kind >> 1)];
+        const int h = kind & 1;
+        if (kind < 2) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[h][0] + off), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[h][1] + off), LDS_PTR(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[h][0] + off), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[h][1] + off), LDS_PTR(dst + 8192), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r = lane & 15, g = lane >> 4, sr = (r >> 1) & 7;
+    const int co0 = (g ^ sr) << 4, co1 = ((4 + g) ^ sr) << 4;        // byte offsets of the two k-steps' 16-B chunks
+    const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](const char* buf, int h) {
+        const char* q = buf + h * HALF + a_row;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
+            af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
+        }
+    };
+    auto read_b = [&](const char* buf, int h, bf16x8 (&bf)[2][2]) {
+        const char* q = buf + (2 + h) * HALF + b_row;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bf[nt][0] = *(const bf16x8*)(q + nt * 2048 + co0);
+            bf[nt][1] = *(const bf16x8*)(q + nt * 2048 + co1);
+        }
+    };
+    auto mma = [&](int ha, int hb, bf16x8 (&bf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[ha * 4 + mt][hb * 2 + nt] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto retire_reads_then_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    const int KT = p.ktiles;
+    // ---- prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight ------------------------------------
+    stage(2, 0); stage(0, 0); stage(3, 0); stage(1, 0);
+    if (KT > 1) {
+        stage(2, 1); stage(0, 1); stage(3, 1);
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+    for (int t = 0; t < KT; ++t) {
+        const char* buf = smem + (t & 1) * BUF;
+        // q0
+        read_b(buf, 0, b0);
+        read_a(buf, 0);
+        if (t + 1 < KT) stage(1, t + 1);
+        retire_reads_then_barrier();
+        mma(0, 0, b0);
+        __builtin_amdgcn_s_barrier();
+        // q1
+        read_b(buf, 1, b1);
+        if (t + 2 < KT) stage(2, t + 2);
+        retire_reads_then_barrier();
+        mma(0, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // q2
+        read_a(buf, 1);
+        if (t + 2 < KT) stage(0, t + 2);
+        retire_reads_then_barrier();
+        mma(1, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // q3
+        if (t + 2 < KT) {
+            stage(3, t + 2);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0, b0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
+    __syncthreads();                             // LDS is free for the epilogue
+
+    // visit the wave's 128x64 accumulator: (row, col) inside the block tile
+    auto foreach = [&](auto&& f) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f(wr * 128 + mi * 16 + g * 4 + j, wc * 64 + ni * 16 + r, ni, acc[mi][ni][j]);
+    };
+
+    if constexpr (EPI == EPI_STATS) {
+        if (p.stats != nullptr) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + BM <= p.M) {
+                foreach([&](int, int, int ni, float v) { s1[ni] += v; s2[ni] += v * v; });
+            } else {
+                foreach([&](int row, int, int ni, float v) {
+                    const float x = (m0 + row < p.M) ? v : 0.f;
+                    s1[ni] += x;
+                    s2[ni] += x * x;
+                });
+            }
+            float* red = (float*)smem;  // [2][2 (wr)][BN]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s1[i] += __shfl_xor(s1[i], 16);
+                s1[i] += __shfl_xor(s1[i], 32);
+                s2[i] += __shfl_xor(s2[i], 16);
+                s2[i] += __shfl_xor(s2[i], 32);
+                if (lane < 16) {
+                    red[(0 * 2 + wr) * BN + wc * 64 + i * 16 + lane] = s1[i];
+                    red[(1 * 2 + wr) * BN + wc * 64 + i * 16 + lane] = s2[i];
+                }
+            }
+            __syncthreads();
+            {
+                const int which = tid >> 8, col = tid & 255;
+                const float s = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+                if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
+            }
+            __syncthreads();
+        }
+    }
+
+    auto out_pixel = [&](int m) -> int64_t {
+        if (p.out_dense) return m;
+        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+        const uint32_t oy = fd_div(rem, p.div_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        return (int64_t)b * p.out_img + (int64_t)(oy * p.osy + p.ooy) * p.out_row + (ox * p.osx + p.oox);
+    };
+    // bf16 tile through LDS so that every row leaves as 16-byte pieces
+    constexpr int PITCH = BN * 2 + 16;
+    foreach([&](int row, int col, int, float v) { *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v; });
+    __syncthreads();
+    constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
+    bf16_t* out = (bf16_t*)p.out;
+#pragma unroll 4
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = it * NT + tid;
+        const int row = c / CPR, cc = c - row * CPR;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if (m < p.M && n < p.N) {
+            bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
+            const int64_t oi = out_pixel(m) * p.out_pitch + n;
+            if (p.addend) {
+                const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+            }
+            *(bf16x8*)(out + oi) = v;
+        }
+    }
+}
+
+constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16);   // the epilogue's transposed tile (135,168 B) > 2 buffers + k table
+
+// Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, at least 128 tiles of
+// 256x256 (half the CUs), and either a long reduction (>= 24 k-tiles: the per-tile prologue / epilogue is not overlapped
+// by a second block as in the 128x128 kernel) or at most one round of tiles.  Measured (tools/check_igemm8.py, B = 32):
+// 256->512 @40^2 161 -> 129 us, 512->1024 @20^2 154 -> 118 us, 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.
+// FVA_IGEMM8=0 turns it off (A/B and bisection aid).
+inline bool igemm8_enabled() {
+    static bool v = [] {
+        const char* e = getenv("FVA_IGEMM8");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps) {
+    if (!igemm8_enabled() || dtype != FVA_BF16 || N % 256 || C % 64) return false;
+    const int64_t ktiles = (int64_t)ntaps * (C / 64), tiles = (int64_t)cdiv(M, 256) * (N / 256);
+    if (ktiles > 496 || tiles < 128) return false;
+    return ktiles >= 24 || (ktiles >= 8 && tiles <= 256);
+}
+
+template <int EPI>
+int launch_igemm8(const IgemmParams& p, hipStream_t s) {
+    IgemmParams q = p;
+    q.nblocks = p.N / 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm8_kernel<EPI>), dim3(cdiv(p.M, 256) * q.nblocks), dim3(512), IGEMM8_SMEM, s, q);
+    FVA_LAUNCH_CHECK("igemm8_kernel");
+    return FVA_OK;
+}
+
 inline bool wide_tile(int N) { return N >= 128; }
 
 // Tile configuration of the wide (N >= 128) bf16 kernels: BM x 128 x NSTAGE.  FVA_IGEMM_TILE = "128x2" | "128x3" |
@@ -411,6 +692,9 @@ inline int tile_bm(int dtype, int M, int N) {
 template <int EPI>
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
     if (dtype == FVA_BF16) {
+        if constexpr (EPI != EPI_HEAD) {
+            if (!p.halfrow && use_igemm8(dtype, p.M, p.N, p.C, p.ktiles / p.kt_per_tap)) return launch_igemm8<EPI>(p, s);
+        }
         if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI, 2>(p, s);
         const int st = wide_cfg().stages;
         if (tile_bm(dtype, p.M, p.N) == 256)
@@ -610,6 +894,7 @@ int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
     if (!d) return 0;
     const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
     const int64_t M = (int64_t)d->B * OH * OW;
+    if (!halfrow_mode(d->dtype, d->Cin) && use_igemm8(d->dtype, M, d->Cout, d->Cin, d->ksize * d->ksize)) return cdiv(M, 256);
     return cdiv(M, tile_bm(d->dtype, (int)M, d->Cout));
 }
 
