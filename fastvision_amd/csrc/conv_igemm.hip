@@ -402,11 +402,26 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
 //   WAR: every phase retires its LDS reads (lgkmcnt(0)) before its first barrier; a half-tile is re-staged at the earliest
 //        one phase after its last read, so the re-staging wave has passed a barrier that every reader reached after
 //        retiring (B-h0: read q0, staged q1; A-h0: q0 -> q2; B-h1: q1 -> q3; A-h1: q2 -> q0 of the next k-tile).
-template <int EPI>
-__global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p) {
+// Stream-K (SK = true): a persistent grid of one block per CU; the launch's work, tiles x k-tiles, is cut into equal
+// contiguous runs, so a run may end inside a tile.  The block that computes a tile's FIRST k-tiles owns the tile: it is the
+// last thing that block does, and by then the blocks after it (whose runs BEGIN with the rest of that tile) have long
+// stored their fp32 partial accumulators to a slab and raised a flag; the owner adds the slabs in block order
+// (deterministic) and runs the epilogue.  Nobody waits before producing its own partial, so there is no cyclic wait;
+// polls are bounded all the same.  Hand-off: stores, vmcnt(0), barrier, agent-scope release, flag = launch epoch |
+// poll, agent-scope acquire, barrier, plain loads (cdna_hip_programming.md G16).
+struct StreamK {
+    float* slabs;        // [grid][32][512] f32x4: a block's accumulators, vector-major
+    int32_t* flags;      // [grid] launch epoch of the slab + [grid] poll time-outs (diagnostic)
+    int32_t epoch;
+    int32_t tiles;
+};
+
+template <int EPI, bool SK>
+__global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const StreamK sk) {
     using T = bf16_t;
     constexpr int BM = 256, BN = 256, NT = 512, BK = 64;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;   // bytes
+    constexpr int EPI_BYTES = BM * (BN * 2 + 16);     // the epilogue's transposed bf16 tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
@@ -414,34 +429,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int mblk = logical / p.nblocks, nblk = logical - mblk * p.nblocks;
-    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int KT = p.ktiles;
 
-    // ---- per-lane source rows of the LDS-DMA pieces: piece (i, w) of a half-tile = its rows (i*8 + w)*8 .. +8 -------
-    const T* a_ptr[2][2];
-    const T* b_ptr[2][2];
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ (((w & 1) << 2) + (lane >> 4));   // source chunk landing at LDS slot (lane & 7)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rh = (i * 8 + w) * 8 + lrow;                   // row inside the half-tile, 0..127
-            int m = m0 + (rh >> 6) * 128 + h * 64 + (rh & 63);
-            m = m < p.M ? m : p.M - 1;
-            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
-            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
-            const uint32_t oy = fd_div(rem, p.div_ow);
-            const uint32_t ox = rem - oy * (uint32_t)p.OW;
-            const int64_t pix = (int64_t)b * p.in_img + (int64_t)(oy * p.sy + p.y0) * p.in_row + (ox * p.sx + p.x0);
-            a_ptr[h][i] = (const T*)p.in + pix * p.C + chunk * 8;
-            int n = n0 + (rh >> 5) * 64 + h * 32 + (rh & 31);
-            n = n < p.N ? n : p.N - 1;
-            b_ptr[h][i] = (const T*)p.wt + (int64_t)n * p.C + chunk * 8;
-        }
-
-    int* ktab = (int*)(smem + 2 * BUF);
-    for (int e = tid; e < p.ktiles; e += NT) {
+    int* ktab = (int*)(smem + EPI_BYTES);   // behind everything the epilogue touches: it lives across tiles
+    for (int e = tid; e < KT; e += NT) {
         const int t = e / p.kt_per_tap, kk = e - t * p.kt_per_tap;
         int tp = 0, tw = 0;
 #pragma unroll
@@ -450,195 +441,316 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p) {
         ktab[2 * e] = tp * p.C + kk * BK;
         ktab[2 * e + 1] = tw * p.N * p.C + kk * BK;
     }
-    __syncthreads();
 
-    // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1
-    auto stage = [&](int kind, int kt) {
-        char* dst = smem + (kt & 1) * BUF + kind * HALF + w * 1024;
-        const int off = ktab[2 * kt + (kind >> 1)];
-        const int h = kind & 1;
-        if (kind < 2) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[h][0] + off), LDS_PTR(dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[h][1] + off), LDS_PTR(dst + 8192), 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[h][0] + off), LDS_PTR(dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[h][1] + off), LDS_PTR(dst + 8192), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ (((w & 1) << 2) + (lane >> 4));   // source chunk landing at LDS slot (lane & 7)
     const int r = lane & 15, g = lane >> 4, sr = (r >> 1) & 7;
     const int co0 = (g ^ sr) << 4, co1 = ((4 + g) ^ sr) << 4;        // byte offsets of the two k-steps' 16-B chunks
     const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
-    auto read_a = [&](const char* buf, int h) {
-        const char* q = buf + h * HALF + a_row;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
-            af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
-        }
-    };
-    auto read_b = [&](const char* buf, int h, bf16x8 (&bf)[2][2]) {
-        const char* q = buf + (2 + h) * HALF + b_row;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            bf[nt][0] = *(const bf16x8*)(q + nt * 2048 + co0);
-            bf[nt][1] = *(const bf16x8*)(q + nt * 2048 + co1);
-        }
-    };
-    auto mma = [&](int ha, int hb, bf16x8 (&bf)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[ha * 4 + mt][hb * 2 + nt] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto retire_reads_then_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
 
-    const int KT = p.ktiles;
-    // ---- prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight ------------------------------------
-    stage(2, 0); stage(0, 0); stage(3, 0); stage(1, 0);
-    if (KT > 1) {
-        stage(2, 1); stage(0, 1); stage(3, 1);
-        wait_vmcnt<6>();
+    // this block's run of (tile, k-tile) units (the host keeps tiles * k-tiles * grid below 2^31)
+    int u, u_end;
+    if constexpr (SK) {
+        const int total = sk.tiles * KT;
+        u = (int)((int64_t)total * logical / nwg);
+        u_end = (int)((int64_t)total * (logical + 1) / nwg);
     } else {
-        wait_vmcnt<0>();
+        u = logical * KT;
+        u_end = u + KT;
     }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
-    for (int t = 0; t < KT; ++t) {
-        const char* buf = smem + (t & 1) * BUF;
-        // q0
-        read_b(buf, 0, b0);
-        read_a(buf, 0);
-        if (t + 1 < KT) stage(1, t + 1);
-        retire_reads_then_barrier();
-        mma(0, 0, b0);
-        __builtin_amdgcn_s_barrier();
-        // q1
-        read_b(buf, 1, b1);
-        if (t + 2 < KT) stage(2, t + 2);
-        retire_reads_then_barrier();
-        mma(0, 1, b1);
-        __builtin_amdgcn_s_barrier();
-        // q2
-        read_a(buf, 1);
-        if (t + 2 < KT) stage(0, t + 2);
-        retire_reads_then_barrier();
-        mma(1, 1, b1);
-        __builtin_amdgcn_s_barrier();
-        // q3
-        if (t + 2 < KT) {
-            stage(3, t + 2);
+    for (; u < u_end;) {
+        const int tile = u / KT;
+        const int kt0 = u - tile * KT;
+        const int kt1 = KT - kt0 < u_end - u ? KT : kt0 + (u_end - u);
+        u += kt1 - kt0;
+        const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
+        const int m0 = mblk * BM, n0 = nblk * BN;
+        __syncthreads();   // ktab is written / the previous tile's epilogue is done with LDS
+
+        // ---- per-lane source rows of the LDS-DMA pieces: piece (i, w) of a half-tile = its rows (i*8 + w)*8 .. +8 ---
+        // (32-bit byte offsets from the tensor bases: the host checks that both operands are smaller than 2 GiB)
+        uint32_t a_off[2][2], b_off[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rh = (i * 8 + w) * 8 + lrow;                   // row inside the half-tile, 0..127
+                int m = m0 + (rh >> 6) * 128 + h * 64 + (rh & 63);
+                m = m < p.M ? m : p.M - 1;
+                const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+                const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+                const uint32_t oy = fd_div(rem, p.div_ow);
+                const uint32_t ox = rem - oy * (uint32_t)p.OW;
+                const uint32_t pix = b * (uint32_t)p.in_img + (oy * p.sy + p.y0) * (uint32_t)p.in_row + (ox * p.sx + p.x0);
+                a_off[h][i] = (pix * (uint32_t)p.C + chunk * 8) * 2;
+                int n = n0 + (rh >> 5) * 64 + h * 32 + (rh & 31);
+                n = n < p.N ? n : p.N - 1;
+                b_off[h][i] = ((uint32_t)n * (uint32_t)p.C + chunk * 8) * 2;
+            }
+
+        // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1; kt is absolute, the LDS buffer alternates from this run's first k-tile
+        auto stage = [&](int kind, int kt, int koff) {
+            char* dst = smem + ((kt - kt0) & 1) * BUF + kind * HALF + w * 1024;
+            const uint32_t off = (uint32_t)koff * 2;   // tap offsets may be "negative": wraps in 32 bits
+            const int h = kind & 1;
+            if (kind < 2) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)p.in + (uint32_t)(a_off[h][0] + off)), LDS_PTR(dst), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)p.in + (uint32_t)(a_off[h][1] + off)), LDS_PTR(dst + 8192), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)p.wt + (uint32_t)(b_off[h][0] + off)), LDS_PTR(dst), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)p.wt + (uint32_t)(b_off[h][1] + off)), LDS_PTR(dst + 8192), 16, 0, 0);
+            }
+        };
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);   // keep the clear ahead of the prologue's LDS-DMA (no register wait after it)
+
+        bf16x8 af[4][2], b0[2][2], b1[2][2];
+        auto read_a = [&](const char* buf, int h) {
+            const char* q = buf + h * HALF + a_row;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
+                af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
+            }
+        };
+        auto read_b = [&](const char* buf, int h, bf16x8 (&bf)[2][2]) {
+            const char* q = buf + (2 + h) * HALF + b_row;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bf[nt][0] = *(const bf16x8*)(q + nt * 2048 + co0);
+                bf[nt][1] = *(const bf16x8*)(q + nt * 2048 + co1);
+            }
+        };
+        auto mma = [&](int ha, int hb, bf16x8 (&bf)[2][2]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[ha * 4 + mt][hb * 2 + nt] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto retire_reads_then_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+
+        // ---- prologue: first k-tile complete, three half-tiles of the second in flight ----------------------------
+        // the offset table is read one phase ahead of its use (kA1: A of k-tile t+1; kA2 / kB2: A / B of k-tile t+2), so that a
+        // phase's LDS-DMA does not queue behind a fresh LDS read
+        auto kofs = [&](int kt, int ab) { return ktab[2 * (kt < KT ? kt : KT - 1) + ab]; };
+        {
+            const int a0 = kofs(kt0, 0), b0k = kofs(kt0, 1);
+            stage(2, kt0, b0k); stage(0, kt0, a0); stage(3, kt0, b0k); stage(1, kt0, a0);
+        }
+        int kA1 = kofs(kt0 + 1, 0), kA2 = kofs(kt0 + 2, 0), kB2 = kofs(kt0 + 2, 1);
+        if (kt0 + 1 < kt1) {
+            const int b1k = kofs(kt0 + 1, 1);
+            stage(2, kt0 + 1, b1k); stage(0, kt0 + 1, kA1); stage(3, kt0 + 1, b1k);
             wait_vmcnt<6>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        mma(1, 0, b0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
-    __syncthreads();                             // LDS is free for the epilogue
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
-    // visit the wave's 128x64 accumulator: (row, col) inside the block tile
-    auto foreach = [&](auto&& f) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) f(wr * 128 + mi * 16 + g * 4 + j, wc * 64 + ni * 16 + r, ni, acc[mi][ni][j]);
-    };
-
-    if constexpr (EPI == EPI_STATS) {
-        if (p.stats != nullptr) {
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + BM <= p.M) {
-                foreach([&](int, int, int ni, float v) { s1[ni] += v; s2[ni] += v * v; });
+        for (int t = kt0; t < kt1; ++t) {
+            const char* buf = smem + ((t - kt0) & 1) * BUF;
+            // q0
+            read_b(buf, 0, b0);
+            read_a(buf, 0);
+            if (t + 1 < kt1) stage(1, t + 1, kA1);
+            retire_reads_then_barrier();
+            mma(0, 0, b0);
+            __builtin_amdgcn_s_barrier();
+            // q1
+            read_b(buf, 1, b1);
+            if (t + 2 < kt1) stage(2, t + 2, kB2);
+            retire_reads_then_barrier();
+            mma(0, 1, b1);
+            __builtin_amdgcn_s_barrier();
+            // q2
+            read_a(buf, 1);
+            if (t + 2 < kt1) stage(0, t + 2, kA2);
+            retire_reads_then_barrier();
+            mma(1, 1, b1);
+            __builtin_amdgcn_s_barrier();
+            // q3
+            if (t + 2 < kt1) {
+                stage(3, t + 2, kB2);
+                wait_vmcnt<6>();
             } else {
-                foreach([&](int row, int, int ni, float v) {
-                    const float x = (m0 + row < p.M) ? v : 0.f;
-                    s1[ni] += x;
-                    s2[ni] += x * x;
-                });
+                wait_vmcnt<0>();
             }
-            float* red = (float*)smem;  // [2][2 (wr)][BN]
+            kA1 = kA2;                       // next iteration: A of k-tile (t+1)+1
+            kA2 = kofs(t + 3, 0);            // read under this phase's MFMAs
+            kB2 = kofs(t + 3, 1);
+            __builtin_amdgcn_s_barrier();
+            mma(1, 0, b0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
+        __syncthreads();                             // LDS is free for the epilogue
+        // everything below derives its addresses from this copy: computed after the loop, not carried (spilled) through it
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int lane_e = tid_e & 63, r_e = lane_e & 15, g_e = lane_e >> 4, wr_e = tid_e >> 8, wc_e = (tid_e >> 6) & 3;
+
+        if constexpr (SK) {
+            if (kt0 > 0) {
+                // the rest of a tile another block owns: hand the partial accumulators over and go on
+                f32x4* slab = (f32x4*)sk.slabs + (int64_t)logical * (32 * NT) + tid_e;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s1[i] += __shfl_xor(s1[i], 16);
-                s1[i] += __shfl_xor(s1[i], 32);
-                s2[i] += __shfl_xor(s2[i], 16);
-                s2[i] += __shfl_xor(s2[i], 32);
-                if (lane < 16) {
-                    red[(0 * 2 + wr) * BN + wc * 64 + i * 16 + lane] = s1[i];
-                    red[(1 * 2 + wr) * BN + wc * 64 + i * 16 + lane] = s2[i];
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) slab[(i * 4 + j) * NT] = acc[i][j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(sk.flags + logical, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                continue;
+            }
+            if (kt1 < KT) {
+                // owner of a tile that continues in the following blocks' runs: add their slabs in block order
+                const int64_t total = (int64_t)sk.tiles * KT;
+                int remaining = KT - kt1;
+                for (int j = logical + 1; remaining > 0 && j < nwg; ++j) {
+                    const int64_t run = total * (j + 1) / nwg - total * j / nwg;
+                    remaining -= run < remaining ? (int)run : remaining;
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(sk.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch && spins < (1 << 22)) {
+                            __builtin_amdgcn_s_sleep(16);
+                            ++spins;
+                        }
+                        if (spins >= (1 << 22)) __hip_atomic_fetch_add(sk.flags + nwg + logical, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+                    const f32x4* slab = (const f32x4*)sk.slabs + (int64_t)j * (32 * NT) + tid_e;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {   // four vectors at a time: the accumulators already fill the register file
+                        f32x4 t4[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) t4[jj] = slab[(i * 4 + jj) * NT];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[i][jj] += t4[jj];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
-            __syncthreads();
-            {
-                const int which = tid >> 8, col = tid & 255;
-                const float s = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
-                if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
-            }
-            __syncthreads();
         }
-    }
 
-    auto out_pixel = [&](int m) -> int64_t {
-        if (p.out_dense) return m;
-        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
-        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
-        const uint32_t oy = fd_div(rem, p.div_ow);
-        const uint32_t ox = rem - oy * (uint32_t)p.OW;
-        return (int64_t)b * p.out_img + (int64_t)(oy * p.osy + p.ooy) * p.out_row + (ox * p.osx + p.oox);
-    };
-    // bf16 tile through LDS so that every row leaves as 16-byte pieces
-    constexpr int PITCH = BN * 2 + 16;
-    foreach([&](int row, int col, int, float v) { *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v; });
-    __syncthreads();
-    constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
-    bf16_t* out = (bf16_t*)p.out;
-#pragma unroll 4
-    for (int it = 0; it < ITERS; ++it) {
-        const int c = it * NT + tid;
-        const int row = c / CPR, cc = c - row * CPR;
-        const int m = m0 + row, n = n0 + cc * 8;
-        if (m < p.M && n < p.N) {
-            bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
-            const int64_t oi = out_pixel(m) * p.out_pitch + n;
-            if (p.addend) {
-                const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
+        // visit the wave's 128x64 accumulator: (row, col) inside the block tile
+        auto foreach = [&](auto&& f) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f(wr_e * 128 + mi * 16 + g_e * 4 + j, wc_e * 64 + ni * 16 + r_e, ni, acc[mi][ni][j]);
+        };
+
+        if constexpr (EPI == EPI_STATS) {
+            if (p.stats != nullptr) {
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (m0 + BM <= p.M) {
+                    foreach([&](int, int, int ni, float v) { s1[ni] += v; s2[ni] += v * v; });
+                } else {
+                    foreach([&](int row, int, int ni, float v) {
+                        const float x = (m0 + row < p.M) ? v : 0.f;
+                        s1[ni] += x;
+                        s2[ni] += x * x;
+                    });
+                }
+                float* red = (float*)smem;  // [2][2 (wr)][BN]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1[i] += __shfl_xor(s1[i], 16);
+                    s1[i] += __shfl_xor(s1[i], 32);
+                    s2[i] += __shfl_xor(s2[i], 16);
+                    s2[i] += __shfl_xor(s2[i], 32);
+                    if (lane_e < 16) {
+                        red[(0 * 2 + wr_e) * BN + wc_e * 64 + i * 16 + lane_e] = s1[i];
+                        red[(1 * 2 + wr_e) * BN + wc_e * 64 + i * 16 + lane_e] = s2[i];
+                    }
+                }
+                __syncthreads();
+                {
+                    const int which = tid_e >> 8, col = tid_e & 255;
+                    const float s = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+                    if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
+                }
+                __syncthreads();
             }
-            *(bf16x8*)(out + oi) = v;
+        }
+
+        auto out_pixel = [&](int m) -> int64_t {
+            if (p.out_dense) return m;
+            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+            const uint32_t oy = fd_div(rem, p.div_ow);
+            const uint32_t ox = rem - oy * (uint32_t)p.OW;
+            return (int64_t)b * p.out_img + (int64_t)(oy * p.osy + p.ooy) * p.out_row + (ox * p.osx + p.oox);
+        };
+        // bf16 tile through LDS so that every row leaves as 16-byte pieces
+        constexpr int PITCH = BN * 2 + 16;
+        foreach([&](int row, int col, int, float v) { *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v; });
+        __syncthreads();
+        constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
+        bf16_t* out = (bf16_t*)p.out;
+#pragma unroll 4
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = it * NT + tid_e;
+            const int row = c / CPR, cc = c - row * CPR;
+            const int m = m0 + row, n = n0 + cc * 8;
+            if (m < p.M && n < p.N) {
+                bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
+                const int64_t oi = out_pixel(m) * p.out_pitch + n;
+                if (p.addend) {
+                    const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                }
+                *(bf16x8*)(out + oi) = v;
+            }
         }
     }
 }
 
-constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16);   // the epilogue's transposed tile (135,168 B) > 2 buffers + k table
+constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16) + 4096;   // the epilogue's transposed tile (> 2 staging buffers) + k table
 
-// Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, at least 128 tiles of
-// 256x256 (half the CUs), and either a long reduction (>= 24 k-tiles: the per-tile prologue / epilogue is not overlapped
-// by a second block as in the 128x128 kernel) or at most one round of tiles.  Measured (tools/check_igemm8.py, B = 32):
-// 256->512 @40^2 161 -> 129 us, 512->1024 @20^2 154 -> 118 us, 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.
-// FVA_IGEMM8=0 turns it off (A/B and bisection aid).
+// Stream-K scratch, registered once by the caller (fva_conv_set_workspace): [grid] slabs of 256 KiB + flags.
+struct SkWorkspace {
+    float* slabs = nullptr;
+    int32_t* flags = nullptr;
+    int grid = 0;
+    int32_t epoch = 0;
+};
+SkWorkspace g_sk;
+constexpr int64_t SK_SLAB_BYTES = 512ll * 128 * 4;
+
+// Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, and
+//  * with stream-K enabled (experiment, see streamk_mode): at least 16 k-tile units per CU (any tile count);
+//  * otherwise at least 128 tiles of 256x256 and either a long reduction (>= 24 k-tiles: the per-tile prologue / epilogue
+//    is not overlapped by a second block as in the 128x128 kernel) or at most one round of tiles.
+// Measured without stream-K (tools/check_igemm8.py, B = 32): 256->512 @40^2 161 -> 129 us, 512->1024 @20^2 154 -> 118 us,
+// 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.  FVA_IGEMM8=0 turns the kernel off.
 inline bool igemm8_enabled() {
     static bool v = [] {
         const char* e = getenv("FVA_IGEMM8");
@@ -646,23 +758,52 @@ inline bool igemm8_enabled() {
     }();
     return v;
 }
+// Stream-K is OFF unless FVA_STREAMK is set (1 = on, 2 = also when the tiles divide evenly: measurement aid) and a
+// workspace is registered.  Measured (tools/check_igemm8.py, CHECK_STREAMK=1): correct and deterministic, but slower than
+// whole tiles at B = 32 (256->512 @40^2: 157 us vs 128 us) -- the per-run pipeline refills, the extra epilogues and the
+// slab hand-off cost more than the 22 % of idle CU time they remove, most of which the second, lighter round of whole
+// tiles already gets back through less contention.  Kept as an experiment for larger grids / batches.
+inline int streamk_mode() {
+    static int v = [] {
+        const char* e = getenv("FVA_STREAMK");
+        return e ? atoi(e) : 0;
+    }();
+    return g_sk.grid > 0 ? v : 0;
+}
+inline bool use_streamk(int64_t tiles, int64_t ktiles) {
+    const int mode = streamk_mode();
+    return mode && tiles * ktiles >= 16ll * g_sk.grid && (mode == 2 || tiles % g_sk.grid != 0);
+}
 inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps) {
     if (!igemm8_enabled() || dtype != FVA_BF16 || N % 256 || C % 64) return false;
     const int64_t ktiles = (int64_t)ntaps * (C / 64), tiles = (int64_t)cdiv(M, 256) * (N / 256);
-    if (ktiles > 496 || tiles < 128) return false;
-    return ktiles >= 24 || (ktiles >= 8 && tiles <= 256);
+    if (ktiles > 496 || ktiles < 8) return false;
+    if (use_streamk(tiles, ktiles)) return true;
+    if (tiles < 128) return false;
+    return ktiles >= 24 || tiles <= 256;
 }
 
 template <int EPI>
 int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     IgemmParams q = p;
     q.nblocks = p.N / 256;
+    const int tiles = cdiv(p.M, 256) * q.nblocks;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm8_kernel<EPI>), dim3(cdiv(p.M, 256) * q.nblocks), dim3(512), IGEMM8_SMEM, s, q);
+    StreamK sk{};
+    if (use_streamk(tiles, p.ktiles)) {
+        sk.slabs = g_sk.slabs;
+        sk.flags = g_sk.flags;
+        sk.epoch = ++g_sk.epoch;
+        sk.tiles = tiles;
+        hipLaunchKernelGGL((igemm8_kernel<EPI, true>), dim3(g_sk.grid), dim3(512), IGEMM8_SMEM, s, q, sk);
+    } else {
+        hipLaunchKernelGGL((igemm8_kernel<EPI, false>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
+    }
     FVA_LAUNCH_CHECK("igemm8_kernel");
     return FVA_OK;
 }
@@ -860,6 +1001,39 @@ int packed_taps(const fva_conv_desc* d, int for_dgrad) {
 }  // namespace
 
 extern "C" {
+
+int64_t fva_conv_workspace_bytes(void) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus < 8) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (int64_t)cus * SK_SLAB_BYTES + (int64_t)cus * 2 * 4;
+}
+
+int fva_conv_set_workspace(void* ws, int64_t bytes) {
+    if (!ws) {
+        g_sk = SkWorkspace();
+        return FVA_OK;
+    }
+    const int64_t need = fva_conv_workspace_bytes();
+    if (need <= 0 || bytes < need) return fva_fail(FVA_ERR_ARG, "fva_conv_set_workspace: %lld bytes given, %lld needed", (long long)bytes, (long long)need);
+    const int cus = (int)(need / (SK_SLAB_BYTES + 8));
+    g_sk.slabs = (float*)ws;
+    g_sk.flags = (int32_t*)((char*)ws + (int64_t)cus * SK_SLAB_BYTES);
+    g_sk.grid = cus;
+    g_sk.epoch = 0;
+    return FVA_OK;
+}
+
+int64_t fva_conv_streamk_timeouts(void) {
+    if (!g_sk.grid) return 0;
+    int32_t host[1024];
+    const int n = g_sk.grid < 1024 ? g_sk.grid : 1024;
+    if (hipMemcpy(host, g_sk.flags + g_sk.grid, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int64_t t = 0;
+    for (int i = 0; i < n; ++i) t += host[i];
+    return t;
+}
 
 int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad) {
     if (!d) return 0;

@@ -58,6 +58,31 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_conv_ws = {}
+
+
+def ensure_conv_workspace(device, force=False):
+    """Register (once per process) the stream-K scratch of the 256x256 conv kernel: a zero-filled device buffer this module
+    keeps alive.  Only when the FVA_STREAMK experiment is switched on (it is slower at B = 32: conv_igemm.hip streamk_mode).
+    One GPU per process (the data-parallel design)."""
+    if _conv_ws:
+        return
+    import os
+    if not force and os.environ.get('FVA_STREAMK', '0') in ('', '0'):
+        _conv_ws[None] = None
+        return
+    lib = _lib.load()
+    nbytes = lib.fva_conv_workspace_bytes()
+    if nbytes > 0:
+        with torch.cuda.device(device):
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            torch.cuda.current_stream(device).synchronize()
+            _lib.call('fva_conv_set_workspace', _p(buf), nbytes)
+        _conv_ws[torch.device(device)] = buf
+    else:
+        _conv_ws[None] = None
+
+
 def require_gpu(t, who):
     if not t.is_cuda:
         raise RuntimeError(f'fastvision_amd.{who}: tensors must live on the GPU -- this package has no CPU path '
@@ -275,6 +300,8 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     B, Cin, H, W = x.shape
     Cout, _, k, _ = weight.shape
     lib = _lib.load()
+    if not _conv_ws:
+        ensure_conv_workspace(x.device)
     d = ConvDesc(_code(dtype), B, H, W, Cin, Cout, k, stride, x_pad, 1)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     M = B * OH * OW

@@ -75,6 +75,15 @@ typedef struct {
 } fva_pack_entry;
 int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t max_elems, void* stream);
 
+/* Optional scratch for the EXPERIMENTAL stream-K form of the 256x256 MFMA kernel (env FVA_STREAMK=1; measured slower than
+ * whole tiles at B = 32, off by default): one 256-KiB accumulator slab per CU + flags.  The caller owns the buffer, zero-fills it once,
+ * registers it once per process (one GPU per process) and keeps it alive; conv launches that use it must not overlap
+ * each other (they are issued on one stream).  Without it those layers run whole tiles per block.
+ * fva_conv_streamk_timeouts() (diagnostic, synchronises): polls that gave up -- must stay 0. */
+int64_t fva_conv_workspace_bytes(void);
+int fva_conv_set_workspace(void* workspace, int64_t bytes);
+int64_t fva_conv_streamk_timeouts(void);
+
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
  * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
