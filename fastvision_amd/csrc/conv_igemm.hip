@@ -418,7 +418,6 @@ struct StreamK {
 
 template <int EPI, bool SK>
 __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const StreamK sk) {
-    using T = bf16_t;
     constexpr int BM = 256, BN = 256, NT = 512, BK = 64;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;   // bytes
     constexpr int EPI_BYTES = BM * (BN * 2 + 16);     // the epilogue's transposed bf16 tile
@@ -774,8 +773,10 @@ inline bool use_streamk(int64_t tiles, int64_t ktiles) {
     const int mode = streamk_mode();
     return mode && tiles * ktiles >= 16ll * g_sk.grid && (mode == 2 || tiles % g_sk.grid != 0);
 }
-inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps) {
+// in_pixels: pixels of the (halo) input tensor -- the kernel addresses both operands with 32-bit byte offsets
+inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in_pixels) {
     if (!igemm8_enabled() || dtype != FVA_BF16 || N % 256 || C % 64) return false;
+    if (in_pixels * C * 2 >= (1ll << 31) || (int64_t)(ntaps + 1) * N * C * 2 >= (1ll << 31)) return false;
     const int64_t ktiles = (int64_t)ntaps * (C / 64), tiles = (int64_t)cdiv(M, 256) * (N / 256);
     if (ktiles > 496 || ktiles < 8) return false;
     if (use_streamk(tiles, ktiles)) return true;
@@ -834,7 +835,8 @@ template <int EPI>
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
     if (dtype == FVA_BF16) {
         if constexpr (EPI != EPI_HEAD) {
-            if (!p.halfrow && use_igemm8(dtype, p.M, p.N, p.C, p.ktiles / p.kt_per_tap)) return launch_igemm8<EPI>(p, s);
+            if (!p.halfrow && use_igemm8(dtype, p.M, p.N, p.C, p.ktiles / p.kt_per_tap, (int64_t)(p.M / p.OHW + 1) * p.in_img))
+                return launch_igemm8<EPI>(p, s);
         }
         if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI, 2>(p, s);
         const int st = wide_cfg().stages;
@@ -1068,7 +1070,9 @@ int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
     if (!d) return 0;
     const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
     const int64_t M = (int64_t)d->B * OH * OW;
-    if (!halfrow_mode(d->dtype, d->Cin) && use_igemm8(d->dtype, M, d->Cout, d->Cin, d->ksize * d->ksize)) return cdiv(M, 256);
+    const int64_t in_img = (int64_t)(d->H + 2 * d->in_pad) * (d->W + 2 * d->in_pad);
+    if (!halfrow_mode(d->dtype, d->Cin) && use_igemm8(d->dtype, M, d->Cout, d->Cin, d->ksize * d->ksize, (M / ((int64_t)OH * OW) + 1) * in_img))
+        return cdiv(M, 256);
     return cdiv(M, tile_bm(d->dtype, (int)M, d->Cout));
 }
 

@@ -6,6 +6,7 @@ Tolerances: fp32 path 1e-4 relative to the tensor scale (north_star allows 1e-3)
 the same fp32 reference fed with bf16-rounded operands, 1e-2 of the tensor scale (bf16 output rounding 2^-9).
 """
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -278,3 +279,24 @@ def test_bn_finalize_large_tables(nblocks):
     assert torch.allclose(rm.cpu().double(), 0.1 * m, rtol=2e-6, atol=1e-7)
     assert int(nbt) == 1
     assert torch.equal(part[:nblocks].cpu(), vals)            # the inputs themselves are not touched
+
+
+def test_igemm_8phase_kernel_equals_128_tile_kernel(tmp_path):
+    """the 256x256 8-phase kernel (default for the long-reduction bf16 layers) against the 128x128 kernel (FVA_IGEMM8=0) on
+    the same inputs: forward + BN partials and dgrad with addend, stride 1 and 2, partial last tile -- bit-identical
+    (same accumulation order), and identical across repeated launches (race screen).  Two child processes: the switch is
+    read once per process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'check_igemm8.py')
+    outs = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / f'ig{flag}.npz')
+        env = dict(os.environ, FVA_IGEMM8=flag, CHECK_SHAPES='small')
+        r = subprocess.run([sys.executable, tool, 'run', out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out)
+        if flag == '1':
+            assert 'stat rows 200' in r.stdout            # 256-row tiles were really used
+    r = subprocess.run([sys.executable, tool, 'compare'] + outs, capture_output=True, text=True)
+    assert r.returncode == 0 and 'all equal' in r.stdout, r.stdout + r.stderr
