@@ -19,6 +19,10 @@
 namespace {
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 struct WgradParams {
     const void* x;
@@ -240,6 +244,237 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves, the 8-phase schedule of conv_igemm.hip's igemm8_kernel applied to the weight gradient (bf16, 3x3
+// layers with Cout % 256 == 0 and Cin = 128 or a multiple of 256): one block per CU, two LDS buffers of four 16-KiB
+// half-tile images [64 pixels][128 channels] (the operand image of wgrad_kernel, so the ds_read_b64_tr_b16 fragment
+// addressing is the same), a 64-pixel k-step consumed in four phases of 16 MFMAs, one half-tile of LDS-DMA per phase,
+// vmcnt(6) once per k-step, the two wave groups (wr = 0 / 1) half a phase apart.
+//   A half h = dY channels n0 + wr*128 + h*64 + [0, 64) of both wave rows; B half h = X columns c0 + wc*64 + h*32 + [0, 32)
+//   of the four wave columns (with Cin = 128 a column tile holds two taps side by side).
+//   q0: read B-h0, A-h0 | stage A-h1(s+1)   q1: read B-h1 | stage B-h0(s+2)   q2: read A-h1 | stage A-h0(s+2)
+//   q3: decode the pixels of step s+3 | stage B-h1(s+2), vmcnt(6).  RAW / WAR as in igemm8_kernel.
+__global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
+    constexpr int BKP = 64, OP = BKP * 256, BUF = 4 * OP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 2, wc = w & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int per_ks = p.ngroups * p.ntn * p.ntc;
+    const int ks = logical / per_ks;
+    logical -= ks * per_ks;
+    const int tg = logical / (p.ntn * p.ntc);
+    logical -= tg * (p.ntn * p.ntc);
+    const int tn = logical / p.ntc, tc = logical - tn * p.ntc;
+    const int n0 = tn * 256, c0 = tc * 256;
+    const int mbeg = ks * p.mchunk;
+    const int mend = (mbeg + p.mchunk < p.M) ? mbeg + p.mchunk : p.M;
+    const int steps = p.mchunk / BKP;
+
+    // ---- LDS-DMA source mapping: one instruction = 4 pixel rows x 256 B of a half-tile image ------------------------
+    const int lrow = lane >> 4;
+    const int f = (lrow << 2) | (w & 3);          // swizzle of this lane's rows R = (i*8 + w)*4 + lrow
+    const int chunk = (lane & 15) ^ f;            // image chunk (8 channels) whose data lands at LDS slot (lane & 15)
+    const uint32_t dy_pixb = (uint32_t)p.dy_pitch * 2u, x_pixb = (uint32_t)p.C * 2u;
+    uint32_t a_colb[2], b_colb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        a_colb[h] = (uint32_t)(n0 + (chunk >> 3) * 128 + h * 64 + (chunk & 7) * 8) * 2u;
+        const int jcol = c0 + (chunk >> 2) * 64 + h * 32 + (chunk & 3) * 8;
+        const int tsub = p.tpt > 1 ? jcol / p.C : 0;
+        const int ccol = p.tpt > 1 ? jcol - tsub * p.C : jcol;
+        const int my_tap = tg * p.tpt + tsub;
+        const bool b_ok = my_tap < p.ntaps && ccol < p.C;   // columns of a tap that does not exist feed unused outputs
+        int tpix = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i == (b_ok ? my_tap : tg * p.tpt)) tpix = p.tap_pix[i];
+        b_colb[h] = (uint32_t)tpix * x_pixb + (uint32_t)(b_ok ? ccol : 0) * 2u;
+    }
+
+    // each wave's DMA touches 8 pixel rows per step; lanes 0..7 decode one each, the others fetch by shuffle
+    const int own_row = (((lane >> 2) & 1) * 8 + w) * 4 + (lane & 3);
+    const char* dy_base = (const char*)p.dy;
+    const char* x_base = (const char*)p.x;
+    auto decode = [&](int step, uint32_t (&dyo)[2], uint32_t (&xo)[2]) {
+        int m = mbeg + step * BKP + own_row;
+        const bool live = m < mend;
+        m = m < p.M ? m : p.M - 1;
+        const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+        const uint32_t oy = fd_div(rem, p.div_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        const uint32_t dpix = b * (uint32_t)p.dy_img + (oy + p.dy_pad) * (uint32_t)p.dy_row + (ox + p.dy_pad);
+        const uint32_t xpix = b * (uint32_t)p.x_img + (oy * p.sy + p.x_y0) * (uint32_t)p.x_row + (ox * p.sx + p.x_x0);
+        const uint32_t own_dy = live ? dpix * dy_pixb : p.dy_zero_off;
+        const uint32_t own_x = xpix * x_pixb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dyo[i] = (uint32_t)__shfl((int)own_dy, i * 4 + lrow);
+            xo[i] = (uint32_t)__shfl((int)own_x, i * 4 + lrow);
+        }
+    };
+    // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1
+    auto stage = [&](int kind, int buf, const uint32_t (&dyo)[2], const uint32_t (&xo)[2]) {
+        char* dst = smem + buf * BUF + kind * OP + w * 1024;
+        const int h = kind & 1;
+        if (kind < 2) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + (dyo[0] + a_colb[h])), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + (dyo[1] + a_colb[h])), LDS_PTR(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (xo[0] + b_colb[h])), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (xo[1] + b_colb[h])), LDS_PTR(dst + 8192), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+
+    // lane-constant addresses of the transposed reads inside a half-tile image (see wgrad_kernel)
+    const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+    const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
+    uint32_t ra[2][4], rb[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = 8 * g + 4 * hh + q;
+        const int fr = (q << 2) | ((2 * g + hh) & 3);
+        const int rbase = row * 256 + 8 * (pp & 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ra[hh][t] = lds0 + rbase + (((wr * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) rb[hh][t] = lds0 + rbase + (((wc * 4 + t * 2 + (pp >> 1)) ^ fr) << 4);
+    }
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](uint32_t boff, auto kind_tag) {
+        constexpr int KO = decltype(kind_tag)::value * OP;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            af[mt][0] = cat8(tr_read<KO>(ra[0][mt] + boff), tr_read<KO>(ra[1][mt] + boff));
+            af[mt][1] = cat8(tr_read<KO + 8192>(ra[0][mt] + boff), tr_read<KO + 8192>(ra[1][mt] + boff));
+        }
+    };
+    auto read_b = [&](uint32_t boff, auto kind_tag, bf16x8 (&bf)[2][2]) {
+        constexpr int KO = decltype(kind_tag)::value * OP;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bf[nt][0] = cat8(tr_read<KO>(rb[0][nt] + boff), tr_read<KO>(rb[1][nt] + boff));
+            bf[nt][1] = cat8(tr_read<KO + 8192>(rb[0][nt] + boff), tr_read<KO + 8192>(rb[1][nt] + boff));
+        }
+    };
+    auto mma = [&](int ha, int hb, bf16x8 (&bf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[ha * 4 + mt][hb * 2 + nt] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][kk], bf[nt][kk], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // the transposed reads are inline asm (invisible to the compiler's counters): retire them by hand before the barrier
+    // that precedes the MFMAs, and keep the MFMAs behind it
+    auto retire_reads_then_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: step 0 complete, three half-tiles of step 1 in flight; offsets of steps 1 and 2 decoded ------------
+    uint32_t d1[2], x1[2], d2[2], x2[2];
+    {
+        uint32_t d0[2], x0[2];
+        decode(0, d0, x0);
+        stage(2, 0, d0, x0); stage(0, 0, d0, x0); stage(3, 0, d0, x0); stage(1, 0, d0, x0);
+    }
+    decode(1, d1, x1);
+    decode(2, d2, x2);
+    if (steps > 1) {
+        stage(2, 1, d1, x1); stage(0, 1, d1, x1); stage(3, 1, d1, x1);
+        wait_vmcnt_n<6>();
+    } else {
+        wait_vmcnt_n<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        const uint32_t boff = (uint32_t)cur * BUF;
+        // q0
+        read_b(boff, K2{}, b0);
+        read_a(boff, K0{});
+        if (s + 1 < steps) stage(1, cur ^ 1, d1, x1);
+        retire_reads_then_barrier();
+        mma(0, 0, b0);
+        __builtin_amdgcn_s_barrier();
+        // q1
+        read_b(boff, K3{}, b1);
+        if (s + 2 < steps) stage(2, cur, d2, x2);
+        retire_reads_then_barrier();
+        mma(0, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // q2
+        read_a(boff, K1{});
+        if (s + 2 < steps) stage(0, cur, d2, x2);
+        retire_reads_then_barrier();
+        mma(1, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // q3
+        if (s + 2 < steps) {
+            stage(3, cur, d2, x2);
+            wait_vmcnt_n<6>();
+        } else {
+            wait_vmcnt_n<0>();
+        }
+        d1[0] = d2[0]; d1[1] = d2[1]; x1[0] = x2[0]; x1[1] = x2[1];
+        decode(s + 3, d2, x2);                       // under this phase's MFMAs
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0, b0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- partial tile -> slab[ks][tap][N][C] --------------------------------------------------------------------------
+    float* out = p.slab + (int64_t)ks * p.ntaps * p.N * p.C;
+    const int r = lane & 15;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int j = wc * 64 + ni * 16 + r;     // column inside the tile
+            int tap, c;
+            if (p.tpt > 1) {
+                const int ts = j / p.C;
+                tap = tg * p.tpt + ts;
+                c = j - ts * p.C;
+            } else {
+                tap = tg;
+                c = c0 + j;
+            }
+            if (c < p.C && tap < p.ntaps) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int n = n0 + wr * 128 + mi * 16 + g * 4 + jj;
+                    if (n < p.N) out[((int64_t)tap * p.N + n) * p.C + c] = acc[mi][ni][jj];
+                }
+            }
+        }
+}
+
 // dw[n][c][t] (+)= sum_ks slab[ks][t][n][c].  Block = 64 consecutive (n,c) pairs x 4 split-K groups: every load is
 // a coalesced 256-B row of the slab, partial sums are combined in a fixed order (deterministic), and the k*k taps
 // of the 64 pairs leave as one contiguous run of the OIHW gradient.
@@ -282,8 +517,27 @@ struct WgradPlan {
     int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW, tpt, ngroups;
 };
 
+// FVA_WGRAD8=0 keeps every layer on the 128x128 kernel (A/B aid)
+inline bool wgrad8_enabled() {
+    static bool v = [] {
+        const char* e = getenv("FVA_WGRAD8");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+// 3x3 bf16 layers whose tiles fill 256 x 256 (Cin = 128 packs two taps per column tile) and that give every CU a run of
+// at least 24 k-steps of 64 pixels (below that the 512-thread block's prologue / slab epilogue dominate: 7x33^2 pixels of a
+// 256->512 layer measured 52 vs 44 us).  Measured at B = 32 (tools/check_wgrad8.py): 256->512 @40^2 177 -> 148 us,
+// 512->1024 @20^2 209 -> 169 us, 128->256 @80^2 176 -> 169 us.
+inline bool use_wgrad8(const fva_conv_desc* d) {
+    if (!wgrad8_enabled() || d->dtype != FVA_BF16 || d->ksize != 3 || d->Cout % 256 || !(d->Cin == 128 || d->Cin % 256 == 0)) return false;
+    const int64_t OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1, M = d->B * OH * OW;
+    const int64_t units = (int64_t)(d->Cout / 256) * cdiv(d->Cin, 256) * (d->Cin == 128 ? 5 : 9);
+    return M * units >= 24ll * 64 * 256;
+}
+
 int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
-    pl.tile = d->dtype == FVA_BF16 ? 128 : 64;
+    pl.tile = d->dtype == FVA_BF16 ? (use_wgrad8(d) ? 256 : 128) : 64;
     pl.OH = (d->H - 1) / d->stride + 1;
     pl.OW = (d->W - 1) / d->stride + 1;
     pl.M = d->B * pl.OH * pl.OW;
@@ -303,12 +557,14 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     int kmax = max_by_m < 1024 ? max_by_m : 1024;
     if (kmax > max_by_ws) kmax = (int)max_by_ws;
     if (kmax < 1) kmax = 1;
-    const double t_full = 2.0 * pl.M * pl.tile * pl.tile / 1.6e12;
+    // the 256x256 8-phase kernel runs one block per CU (256 slots) at ~4.3 TFLOP/s per block
+    const int slots = pl.tile == 256 ? 256 : 512;
+    const double t_full = 2.0 * pl.M * pl.tile * pl.tile / (pl.tile == 256 ? 4.3e12 : 1.6e12);
     const double t_slab = (double)per * 2.0 / 3.0e12 + 0.05e-6;
     int ks = 1;
     double best = 1e30;
     for (int k = 1; k <= kmax; ++k) {
-        const int rounds = cdiv((int64_t)tiles * k, 512);
+        const int rounds = cdiv((int64_t)tiles * k, slots);
         const double cost = rounds * t_full / k + k * t_slab;
         if (cost < best * (1.0 - 1e-9)) { best = cost; ks = k; }
     }
@@ -378,7 +634,14 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     const int grid = pl.ksplit * pl.ngroups * pl.ntn * pl.ntc;
     const int smem = 2 * 2 * 64 * 256;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == FVA_BF16)
+    if (pl.tile == 256) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * 256);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
+    } else if (d->dtype == FVA_BF16)
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);
     else
         hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), smem, s, p);

@@ -300,3 +300,21 @@ def test_igemm_8phase_kernel_equals_128_tile_kernel(tmp_path):
             assert 'stat rows 200' in r.stdout            # 256-row tiles were really used
     r = subprocess.run([sys.executable, tool, 'compare'] + outs, capture_output=True, text=True)
     assert r.returncode == 0 and 'all equal' in r.stdout, r.stdout + r.stderr
+
+
+def test_wgrad_8phase_kernel_matches_128_tile_kernel(tmp_path):
+    """the 256x256 8-phase weight-gradient kernel (default for the large 3x3 bf16 layers) against the 128x128 kernel
+    (FVA_WGRAD8=0) on the same inputs, stride 1 and 2, two-taps-per-tile packing (Cin = 128), ragged pixel counts: equal to
+    fp32 rounding of the different split-K order, and bit-identical across repeated launches.  Two child processes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'check_wgrad8.py')
+    outs = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / f'wg{flag}.npz')
+        env = dict(os.environ, FVA_WGRAD8=flag, CHECK_SHAPES='small')
+        r = subprocess.run([sys.executable, tool, 'run', out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out)
+    r = subprocess.run([sys.executable, tool, 'compare'] + outs, capture_output=True, text=True)
+    assert r.returncode == 0 and 'all within' in r.stdout, r.stdout + r.stderr
