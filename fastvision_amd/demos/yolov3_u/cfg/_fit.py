@@ -1,68 +1,69 @@
 """Demo fit loop -- API mirror of the reference's demos/yolov3_u/cfg/_fit.py (Fit, _Train, _Validate).
 
-Same step contract (cfg/_fit.py:41-56): predict = model(images); optimizer.zero_grad(); loss = criterion(predict,
-target, model); loss.backward(); optimizer.step().  The reference calls ``loss.item()`` twice per batch; here the
-loss is read back once per batch (still one sync, kept for the printed log).
+Step contract (cfg/_fit.py:41-56): predict = model(images); optimizer.zero_grad(); loss = criterion(predict, target,
+model); loss.backward(); optimizer.step().  Training and validation share one epoch runner here; the per-batch log
+line, the best-validation checkpoint and the divide-by-ten-every-fourth-epoch-without-improvement rule are the
+reference's (:10-34).  The loss is read back once per batch (the reference reads it twice), for that log line.
 """
 import time
 
 import torch
 
+LR_FLOOR = 1e-8
+PATIENCE = 3
+_BATCH_LINE = 'epoch : {} batch : {} / {} loss : {:.3f} time : {:.3f}'
 
-def Fit(model, args, optimizer, criterion, metric, train_loader, validation_loader):
-    best_val_loss = float('inf')
-    patient = 0
-    for epoch in range(args.start_epoch, args.max_epochs):
-        s_time = time.time()
-        print('\nEpoch {} learning_rate : {}'.format(epoch + 1, optimizer.param_groups[0]['lr']))
-        loss_train = _Train(model, train_loader, optimizer, criterion, epoch)
-        loss_val = _Validate(model, validation_loader, criterion, epoch)
-        if loss_val < best_val_loss:
-            torch.save(model.state_dict(), f'./epoch_{epoch+1}_loss_{loss_val}.pth')
-            best_val_loss = loss_val
-            patient = 0
-        if patient >= 3:
-            for group in optimizer.param_groups:
-                group['lr'] = group['lr'] * 0.1 if group['lr'] * 0.1 > 1e-8 else 1e-8
-            patient = 0
-        patient += 1
-        print('epoch : {} train_loss : {:.3f} time : {:.3f}'.format(epoch + 1, loss_train, time.time() - s_time))
-        print('epoch : {} val_loss : {:.3f} time : {:.3f}'.format(epoch + 1, loss_val, time.time() - s_time))
+
+def _run_epoch(model, loader, criterion, epoch, optimizer=None, log=print):
+    """One pass over ``loader``; with an optimizer it trains, without one it evaluates under no_grad.  Mean batch loss."""
+    training = optimizer is not None
+    model.train(training)
+    total, count = 0.0, 0
+    with torch.set_grad_enabled(training):
+        for count, (images, target) in enumerate(loader, start=1):
+            tick = time.time()
+            predict = model(images.cuda(non_blocking=True))
+            target = target.cuda(non_blocking=True)
+            if training:
+                optimizer.zero_grad()
+            loss = criterion(predict, target, model)
+            if training:
+                loss.backward()
+                optimizer.step()
+            value = loss.item()
+            total += value
+            if log:
+                log(_BATCH_LINE.format(epoch + 1, count, len(loader), value, time.time() - tick))
+    return total / count
 
 
 def _Train(model, train_loader, optimizer, criterion, epoch, log=print):
-    model.train()
-    loss_batch = []
-    for batch, (images, target) in enumerate(train_loader):
-        s_time = time.time()
-        images = images.cuda(non_blocking=True)
-        target = target.cuda(non_blocking=True)
-        predict = model(images)
-        optimizer.zero_grad()
-        loss = criterion(predict, target, model)
-        loss.backward()
-        optimizer.step()
-        value = loss.item()
-        loss_batch.append(value)
-        if log:
-            log('epoch : {} batch : {} / {} loss : {:.3f} time : {:.3f}'.format(epoch + 1, batch + 1, len(train_loader), value,
-                                                                                 time.time() - s_time))
-    return sum(loss_batch) / len(loss_batch)
+    return _run_epoch(model, train_loader, criterion, epoch, optimizer=optimizer, log=log)
 
 
 def _Validate(model, val_loader, criterion, epoch, log=print):
-    model.eval()
-    loss_batch = []
-    with torch.no_grad():
-        for batch, (images, target) in enumerate(val_loader):
-            s_time = time.time()
-            images = images.cuda(non_blocking=True)
-            target = target.cuda(non_blocking=True)
-            predict = model(images)
-            loss = criterion(predict, target, model)
-            value = loss.item()
-            loss_batch.append(value)
-            if log:
-                log('epoch : {} batch : {} / {} loss : {:.3f} time : {:.3f}'.format(epoch + 1, batch + 1, len(val_loader), value,
-                                                                                     time.time() - s_time))
-    return sum(loss_batch) / len(loss_batch)
+    return _run_epoch(model, val_loader, criterion, epoch, optimizer=None, log=log)
+
+
+def _decay_lr(optimizer, factor=0.1):
+    for group in optimizer.param_groups:
+        group['lr'] = max(group['lr'] * factor, LR_FLOOR)
+
+
+def Fit(model, args, optimizer, criterion, metric, train_loader, validation_loader):
+    best, since_best = float('inf'), 0
+    for epoch in range(args.start_epoch, args.max_epochs):
+        started = time.time()
+        print('\nEpoch {} learning_rate : {}'.format(epoch + 1, optimizer.param_groups[0]['lr']))
+        results = (('train_loss', _Train(model, train_loader, optimizer, criterion, epoch)),
+                   ('val_loss', _Validate(model, validation_loader, criterion, epoch)))
+        val = results[1][1]
+        if val < best:
+            best, since_best = val, 0
+            torch.save(model.state_dict(), f'./epoch_{epoch+1}_loss_{val}.pth')
+        if since_best >= PATIENCE:                 # checked before the increment, as the reference does
+            _decay_lr(optimizer)
+            since_best = 0
+        since_best += 1
+        for name, value in results:
+            print('epoch : {} {} : {:.3f} time : {:.3f}'.format(epoch + 1, name, value, time.time() - started))
