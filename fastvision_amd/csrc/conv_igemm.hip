@@ -189,7 +189,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 for (int e = 0; e < 16; ++e) acc.a[i][j][e] = 0.f;
     }
 
-    // ---- main loop: NSTAGE-deep LDS ring, one raw barrier per k-tile.  Tiles kt+1 .. kt+NSTAGE-2 stay in flight
+    // ---- main loop: NSTAGE-deep LDS ring (2 in every build: deeper rings leave one block per CU and measured slower),
+    // one raw barrier per k-tile.  Tiles kt+1 .. kt+NSTAGE-2 stay in flight
     // across the barrier (counted vmcnt: LDS-DMA retires in issue order), tile kt+NSTAGE-1 is issued right after
     // it into the stage every wave has just finished reading.
     constexpr int LPT = A_ITERS + B_ITERS;  // DMA instructions per wave and tile
@@ -811,25 +812,8 @@ int launch_igemm8(const IgemmParams& p, hipStream_t s) {
 
 inline bool wide_tile(int N) { return N >= 128; }
 
-// Tile configuration of the wide (N >= 128) bf16 kernels: BM x 128 x NSTAGE.  FVA_IGEMM_TILE = "128x2" | "128x3" |
-// "128x4" | "256x2" | "256x3" overrides the default (tuning aid; the default is what the benchmarks run).
-struct WideCfg { int bm, stages; };
-inline WideCfg wide_cfg() {
-    static WideCfg cfg = [] {
-        WideCfg c{128, 2};
-        if (const char* e = getenv("FVA_IGEMM_TILE")) {
-            int bm = 0, st = 0;
-            if (sscanf(e, "%dx%d", &bm, &st) == 2 && (bm == 128 || bm == 256) && st >= 2 && st <= (bm == 128 ? 4 : 3)) c = WideCfg{bm, st};
-        }
-        return c;
-    }();
-    return cfg;
-}
-inline int tile_bm(int dtype, int M, int N) {
-    if (!wide_tile(N)) return 256;
-    if (dtype == FVA_BF16 && wide_cfg().bm == 256 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 384) return 256;
-    return 128;
-}
+// 128x128 tiles for N >= 128, 256x64 for thinner outputs (the rows of BatchNorm partial statistics follow the tile)
+inline int tile_bm(int /*dtype*/, int /*M*/, int N) { return wide_tile(N) ? 128 : 256; }
 
 template <int EPI>
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
@@ -838,13 +822,7 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
             if (!p.halfrow && use_igemm8(dtype, p.M, p.N, p.C, p.ktiles / p.kt_per_tap, (int64_t)(p.M / p.OHW + 1) * p.in_img))
                 return launch_igemm8<EPI>(p, s);
         }
-        if (!wide_tile(p.N)) return launch_one<bf16_t, 256, 64, EPI, 2>(p, s);
-        const int st = wide_cfg().stages;
-        if (tile_bm(dtype, p.M, p.N) == 256)
-            return st == 3 ? launch_one<bf16_t, 256, 128, EPI, 3>(p, s) : launch_one<bf16_t, 256, 128, EPI, 2>(p, s);
-        if (st == 4 && wide_cfg().bm == 128) return launch_one<bf16_t, 128, 128, EPI, 4>(p, s);
-        if (st == 3 && wide_cfg().bm == 128) return launch_one<bf16_t, 128, 128, EPI, 3>(p, s);
-        return launch_one<bf16_t, 128, 128, EPI, 2>(p, s);
+        return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI, 2>(p, s) : launch_one<bf16_t, 256, 64, EPI, 2>(p, s);
     }
     return wide_tile(p.N) ? launch_one<float, 128, 128, EPI, 2>(p, s) : launch_one<float, 256, 64, EPI, 2>(p, s);
 }

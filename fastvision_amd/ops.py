@@ -233,67 +233,6 @@ class _Saved:
     pass
 
 
-# Optional experiment (FVA_WGRAD_STREAM=1): wgrad is off the critical path of backward, so it can be launched on a side stream,
-# concurrently with the same layer's dgrad, so the two fill each other's partially occupied last rounds.
-import os as _os
-_side_streams = {}
-# FVA_WGRAD_STREAM: 0 (default) = wgrad on the launch stream; 1 = side stream, joined right after the layer's dgrad
-# (measured 807 vs 823 img/s: worse); 2 = LOW-priority side stream, joined once at the end of the backward pass
-# (measured 846-856 vs 837-841 img/s: +1-2 %, but +8 ms host time per step and overlapping kernels blur the
-# per-kernel timings the roofline is read from, so it stays opt-in)
-WGRAD_MODE = int(_os.environ.get('FVA_WGRAD_STREAM', '0'))
-OVERLAP_WGRAD = WGRAD_MODE == 1
-_pending_join = {}
-
-
-def _side_stream(device):
-    """A LOW-priority stream (HIP priority 1; torch's own streams are 0 or -1): its kernels are dispatched only when
-    the caller's stream leaves workgroup slots free, i.e. in the partially filled last rounds of the critical path."""
-    st = _side_streams.get(device)
-    if st is None:
-        try:
-            hip = C.CDLL('libamdhip64.so')
-            with torch.cuda.device(device):
-                torch.cuda.current_stream()            # make sure the context exists
-                h = C.c_void_p()
-                if hip.hipStreamCreateWithPriority(C.byref(h), 1, 1) != 0 or not h.value:   # hipStreamNonBlocking, least prio
-                    raise OSError('hipStreamCreateWithPriority failed')
-                st = torch.cuda.ExternalStream(h.value, device=device)
-        except (OSError, AttributeError):
-            st = torch.cuda.Stream(device=device, priority=0)
-        _side_streams[device] = st
-    return st
-
-
-_fork_events = {}   # device -> reusable event marking 'dY ready' on the caller's stream
-_inflight = {}      # device -> tensors a lagging wgrad still reads / writes (kept alive until the join)
-_side_ws = {}       # device -> one workspace shared by all side-stream wgrads (they run in order on that stream)
-
-
-def join_side_stream(device=None):
-    """Make the current stream wait for every wgrad still running on the side stream (end of backward / optimizer)."""
-    for dev, st in list(_side_streams.items()):
-        if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(st)
-            _inflight.pop(dev, None)
-            _pending_join[dev] = False
-
-
-def _defer_join(device):
-    if not _pending_join.get(device):
-        _pending_join[device] = True
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_side_stream(device))
-
-
-def _side_workspace(device, nbytes, side):
-    ws = _side_ws.get(device)
-    if ws is None or ws.numel() < nbytes:
-        if ws is not None:
-            ws.record_stream(side)                     # an in-flight wgrad may still use the old buffer
-        ws = _side_ws[device] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-    return ws
-
-
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
     """SiLU(BN(conv(x))) [+ residual].  x: logical [B,Cin,H,W]; x_ptr/x_pad describe its halo buffer.
     Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape."""
@@ -355,46 +294,15 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
               _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
-    overlap = OVERLAP_WGRAD and need_dx
-    w_param = getattr(s, 'weight', None)
-    lag_ok = (WGRAD_MODE == 2 and w_param is not None and w_param.grad is None
-              and not getattr(w_param, '_post_accumulate_grad_hooks', None))
-    if lag_ok:
-        # The weight gradient may lag behind the critical path: nobody reads it before the end of backward.  That is
-        # only true if autograd will simply adopt the tensor (no existing .grad to add to -> no kernel on the main
-        # stream) and no post-accumulate hook (DP reducer) looks at it; otherwise take the in-order path below.
-        side = _side_stream(dev)
-        ev = _fork_events.get(dev)
-        if ev is None:
-            ev = _fork_events[dev] = torch.cuda.Event()
-        ev.record()                                                # dY is ready at this point of the caller's stream
-        side.wait_event(ev)
-        ws = _side_workspace(dev, ws_bytes, side)
-        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes,
-                  C.c_void_p(side.cuda_stream))
-        # dY and x must outlive the lagging kernel: record_stream lets the allocator recycle them as soon as the side
-        # stream has passed this point (holding them until the end of backward kept 6.5 GB of cold buffers around).
-        # dw is NOT referenced anywhere else: an extra reference would make autograd's AccumulateGrad clone it (on the
-        # main stream, too early) instead of adopting it.
-        dy.record_stream(side)
-        (s.keep if isinstance(getattr(s, 'keep', None), torch.Tensor) else s.x).record_stream(side)
-        _defer_join(dev)
-    elif overlap:
-        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        side.wait_stream(main)                           # dY (and everything before it) is ready
-        with torch.cuda.stream(side):
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
-        dw.record_stream(side)
-    else:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+    # wgrad runs on the launch stream, ahead of dgrad.  (Launching it on a low-priority side stream and joining once at the
+    # end of backward measured +1-2 %, at the price of 8 ms of host time per step and overlapped per-kernel timings: not
+    # worth the machinery -- DESIGN.md section 5.)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
         _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(s.wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
-    if overlap:
-        main.wait_stream(side)                           # dw is complete before anyone downstream can read it
     return dx, dw, dgamma, dbeta
 
 

@@ -58,9 +58,6 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue
-            from . import ops
-            if ops._side_streams:
-                ops.join_side_stream(None)             # gradients computed on the side stream are complete
             ps, (_, tab, sizes, n, mx, _keep) = self._table(gi, group)
             if not ps[0].is_cuda:
                 raise RuntimeError('FusedAdam: parameters must live on the GPU (no CPU path)')

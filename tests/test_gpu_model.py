@@ -5,6 +5,8 @@ Bars (north_star): anchor/target indexing bit-exact; fp32 loss and gradients wit
 100-step loss curve within 1e-3 of the CPU reference.  bf16 results are reported with their own (looser)
 tolerance, stated in each test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -405,3 +407,45 @@ def test_config2_fp32_full_size_vs_oracle():
     rel = np.abs(gn[:, 0] - gn[:, 1]) / np.maximum(gn[:, 1], 1e-12)
     print('cfg2 grad-norm rel dev: median', np.median(rel), 'max', rel.max())
     assert rel.max() < 2e-3
+
+
+def test_demo_fit_loop_trains_validates_and_steps_lr(tmp_path, monkeypatch):
+    """demos/yolov3_u/cfg/_fit.py mirror: _Train / _Validate return the mean batch loss and print the reference's log line;
+    Fit saves the best checkpoint and divides the LR by ten after three epochs without improvement."""
+    import types
+    import fastvision_amd
+    from fastvision_amd.demos.yolov3_u.cfg import _fit as F
+    from fastvision_amd.demos.yolov3_u.models import YoloV3
+    from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+    from fastvision_amd.synthetic import coco_anchors_feature, synthetic_batch
+    monkeypatch.chdir(tmp_path)
+    with fastvision_amd.compute_dtype(torch.float32):
+        torch.manual_seed(1)
+        net = YoloV3(anchors=tuple(a.to('cuda:0') for a in coco_anchors_feature())).to('cuda:0')
+        crit = ComputeLoss()
+        quiet = lambda pred, tg, model: _silently(crit, pred, tg, model)
+        loader = [synthetic_batch(2, 64, seed=s) for s in (1, 2)]
+        opt = fastvision_amd.FusedAdam(net.parameters(), lr=1e-3)
+        lines = []
+        tr = F._Train(net, loader, opt, quiet, 0, log=lines.append)
+        va = F._Validate(net, loader, quiet, 0, log=lines.append)
+        assert np.isfinite(tr) and np.isfinite(va) and len(lines) == 4
+        assert lines[0].startswith('epoch : 1 batch : 1 / 2 loss : ')
+        assert not net.training                                   # _Validate leaves the model in eval mode, as the reference
+        # LR rule: a criterion whose validation loss never improves after the first epoch
+        calls = {'n': 0}
+        def fake_validate(model, loader_, criterion, epoch, log=print):
+            calls['n'] += 1
+            return 1.0 + calls['n']
+        monkeypatch.setattr(F, '_Validate', fake_validate)
+        monkeypatch.setattr(F, '_Train', lambda *a, **k: 0.5)
+        args = types.SimpleNamespace(start_epoch=0, max_epochs=6)
+        F.Fit(net, args, opt, quiet, None, loader, loader)
+        assert abs(opt.param_groups[0]['lr'] - 1e-4) < 1e-12     # one decay, at the epoch where patience reached 3
+        assert os.path.exists(tmp_path / 'epoch_1_loss_2.0.pth')
+
+
+def _silently(crit, pred, tg, model):
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return crit(pred, tg, model)
