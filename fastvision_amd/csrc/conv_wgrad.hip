@@ -117,10 +117,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         const uint32_t xpix = b * (uint32_t)p.x_img + (oy * p.sy + p.x_y0) * (uint32_t)p.x_row + (ox * p.sx + p.x_x0);
         const uint32_t own_dy = live ? dpix * dy_pixb : p.dy_zero_off;
         const uint32_t own_x = xpix * x_pixb;
+        // lanes whose columns do not exist (N or C*taps smaller than the tile) all read ONE 16-byte piece at the start of
+        // the buffer instead of a real row: their products land in outputs that are never stored, and the dead half of a
+        // thin layer's tile then costs no L2 / HBM traffic (32->64 layers: half of the dY rows, a quarter of the X slots)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            nx_dy[i] = (uint32_t)__shfl((int)own_dy, i * 4 + lrow) + a_colb;
-            nx_x[i] = (uint32_t)__shfl((int)own_x, i * 4 + lrow) + b_colb;
+            const uint32_t rd = (uint32_t)__shfl((int)own_dy, i * 4 + lrow), rx = (uint32_t)__shfl((int)own_x, i * 4 + lrow);
+            nx_dy[i] = a_ok ? rd + a_colb : 0u;
+            nx_x[i] = b_ok ? rx + b_colb : 0u;
         }
     };
     auto issue_step = [&](int stage) {
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     const int chunk = (lane & 15) ^ f;            // image chunk (8 channels) whose data lands at LDS slot (lane & 15)
     const uint32_t dy_pixb = (uint32_t)p.dy_pitch * 2u, x_pixb = (uint32_t)p.C * 2u;
     uint32_t a_colb[2], b_colb[2];
+    bool b_live[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         a_colb[h] = (uint32_t)(n0 + (chunk >> 3) * 128 + h * 64 + (chunk & 7) * 8) * 2u;
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
         for (int i = 0; i < 9; ++i)
             if (i == (b_ok ? my_tap : tg * p.tpt)) tpix = p.tap_pix[i];
         b_colb[h] = (uint32_t)tpix * x_pixb + (uint32_t)(b_ok ? ccol : 0) * 2u;
+        b_live[h] = b_ok;   // dead columns (the 10th tap slot of a two-taps-per-tile layer) read one shared 16-byte piece
     }
 
     // each wave's DMA touches 8 pixel rows per step; lanes 0..7 decode one each, the others fetch by shuffle
@@ -325,8 +331,8 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + (dyo[0] + a_colb[h])), LDS_PTR(dst), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GLB_PTR(dy_base + (dyo[1] + a_colb[h])), LDS_PTR(dst + 8192), 16, 0, 0);
         } else {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (xo[0] + b_colb[h])), LDS_PTR(dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (xo[1] + b_colb[h])), LDS_PTR(dst + 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (b_live[h] ? xo[0] + b_colb[h] : 0u)), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(x_base + (b_live[h] ? xo[1] + b_colb[h] : 0u)), LDS_PTR(dst + 8192), 16, 0, 0);
         }
     };
 
