@@ -10,18 +10,20 @@ import torch
 
 from ..detection.tools import non_max_suppression_images, xywh2xyxy
 from ..metrics import CalculateMAP
+from .checkpoints import SaveModel
 
 __all__ = ['Fit']
 
 
 class Fit:
     def __init__(self, model, device, optimizer, scheduler, loss, end_epoch, start_epoch=0, train_loader=None, val_loader=None,
-                 test_loader=None, data_dict=None, log_every=0):
+                 test_loader=None, data_dict=None, log_every=0, save_last='last.pth'):
         self.model, self.device, self.optimizer, self.scheduler, self.loss = model, device, optimizer, scheduler, loss
         self.start_epoch, self.end_epoch = start_epoch, end_epoch
         self.train_loader, self.val_loader, self.test_loader = train_loader, val_loader, test_loader
         self.category_names = {k: v for k, v in enumerate((data_dict or {}).get('categories', []))}
         self.log_every = log_every
+        self.save_last = save_last                  # None / '' skips the per-epoch checkpoint the reference always writes
         self.history = []
 
     def run_epoches(self):
@@ -29,7 +31,8 @@ class Fit:
             self._train(epoch)
             if self.val_loader:
                 self._val()
-                self.model.train()
+            if self.save_last:                      # fit.py:36-41: the whole model + optimizer state after every epoch
+                SaveModel({'model': self.model, 'optimizer': self.optimizer.state_dict()}, self.save_last, weights_only=True)
         if self.test_loader:
             self._test()
 

@@ -158,3 +158,50 @@ def test_checkpoint_helpers_roundtrip(tmp_path):
     assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())
     SqueezeModel(c, ['bn'], False)
     assert not c.bn.weight.requires_grad and c.conv.weight.requires_grad
+
+
+def test_fit_run_epoches_contract(tmp_path, monkeypatch):
+    """utils/fit.py: per batch model -> zero_grad -> loss -> backward -> step; scheduler.step() once per epoch; a
+    'last.pth' checkpoint {'model': state_dict, 'optimizer': ..., 'date': ...} after every epoch (fit.py:29-71)."""
+    import torch
+    from fastvision_amd.utils import Fit
+    monkeypatch.chdir(tmp_path)
+    events = []
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, x, val=False):
+            events.append('forward')
+            return (x * self.w).sum()
+
+    class Opt(torch.optim.SGD):
+        def zero_grad(self, *a, **k):
+            events.append('zero_grad')
+            return super().zero_grad(*a, **k)
+
+        def step(self, *a, **k):
+            events.append('step')
+            return super().step(*a, **k)
+
+    class Sched:
+        def step(self):
+            events.append('sched')
+
+    net = Net()
+    opt = Opt(net.parameters(), lr=0.1)
+
+    def loss(pred, labels):
+        events.append('loss')
+        return pred + labels.sum()
+    loader = [(torch.ones(3), torch.zeros(1)), (torch.full((3,), 2.0), torch.zeros(1))]
+    fit = Fit(net, torch.device('cpu'), opt, Sched(), loss, end_epoch=2, train_loader=loader)
+    fit.run_epoches()
+    per_batch = ['forward', 'zero_grad', 'loss', 'step']
+    assert events == (per_batch * 2 + ['sched']) * 2
+    assert len(fit.history) == 2 and len(fit.history[0]) == 2
+    ckpt = torch.load(tmp_path / 'last.pth', weights_only=False)
+    assert set(ckpt) == {'model', 'optimizer', 'date'} and 'w' in ckpt['model']
+    assert torch.allclose(ckpt['model']['w'], net.w.detach())
