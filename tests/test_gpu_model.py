@@ -449,3 +449,33 @@ def _silently(crit, pred, tg, model):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         return crit(pred, tg, model)
+
+
+def test_bf16_step_same_with_and_without_8phase_kernels(tmp_path):
+    """whole model, B = 32 at 416 px (ragged grids 13/26/52), one bf16 step in child processes:
+    * 8-phase wgrad on / off: forward identical (same loss, bit for bit), weight gradients equal to the fp32 rounding of the
+      different split-K order;
+    * 8-phase igemm on / off: its conv outputs are bit-identical (kernel-level test), but BatchNorm partial sums are grouped
+      by 256 instead of 128 rows, which moves the batch statistics in their last bits and flips bf16 roundings downstream --
+      the step agrees to bf16 noise (loss 1e-4, gradient norms 5e-3 in the median)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'step_dump.py')
+
+    def run(tag, **flags):
+        out = str(tmp_path / f'{tag}.npz')
+        r = subprocess.run([sys.executable, tool, out, '32', '416'], env=dict(os.environ, **flags), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return np.load(out)
+
+    base = run('none', FVA_IGEMM8='0', FVA_WGRAD8='0')
+    wg = run('wgrad8', FVA_IGEMM8='0', FVA_WGRAD8='1')
+    both = run('both')
+    assert wg['loss'][0] == base['loss'][0]
+    for k in base.files:
+        if k.startswith('samp/'):
+            assert np.abs(wg[k] - base[k]).max() <= 1e-5 * (np.abs(base[k]).max() + 1e-12), k
+    assert abs(both['loss'][0] - base['loss'][0]) <= 1e-4 * abs(base['loss'][0])
+    rel = np.array([abs(both[k][0] - base[k][0]) / max(base[k][0], 1e-12) for k in base.files if k.startswith('norm/')])
+    assert np.median(rel) < 5e-3 and rel.max() < 5e-2, (np.median(rel), rel.max())
