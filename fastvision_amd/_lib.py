@@ -61,6 +61,7 @@ PROTOTYPES = {
     'fva_conv_set_workspace': (_I, [_P, _L]),
     'fva_conv_streamk_timeouts': (_L, []),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _L, _P]),

@@ -11,10 +11,6 @@
 
 namespace {
 
-// sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE divide: these kernels are HBM-bound and the
-// divide sequence (~10 VALU ops per element) was competing with the memory pipeline
-__device__ __forceinline__ float sigm_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
-__device__ __forceinline__ float silu_f(float u) { return u * sigm_fast(u); }
 __device__ __forceinline__ float silu_grad(float u) {
     const float s = sigm_fast(u);
     return s * (1.f + u * (1.f - s));

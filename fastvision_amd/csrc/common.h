@@ -79,6 +79,10 @@ struct Vec16<bf16_t> {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE divide: the divide sequence (~10 VALU ops per element)
+// competes with the memory pipeline in the HBM-bound BatchNorm / SiLU kernels and in fused conv epilogues
+__device__ __forceinline__ float sigm_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_f(float u) { return u * sigm_fast(u); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -16,7 +16,7 @@
 
 namespace {
 
-enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_HEAD = 2 };
+enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_HEAD = 2, EPI_BNACT = 3 };   // BNACT: out = SiLU(acc * scale[n] + shift[n]) (+ addend)
 constexpr int MAX_TAPS = 10;
 
 struct IgemmParams {
@@ -25,6 +25,8 @@ struct IgemmParams {
     void* out;
     float* stats;
     const float* bias;
+    const float* scale;  // EPI_BNACT: per-output-channel affine (eval-mode BatchNorm folded in) before SiLU
+    const float* shift;
     int M, N, C;
     int OW, OHW;
     FastDiv div_ow, div_ohw;
@@ -339,6 +341,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     pix_cache = out_pixel(m);
                 }
                 const int64_t oi = pix_cache * p.out_pitch + n;
+                if constexpr (EPI == EPI_BNACT) v = silu_f(v * p.scale[n] + p.shift[n]);
                 out[oi] = p.addend ? ((const float*)p.addend)[oi] + v : v;
             }
         });
@@ -346,6 +349,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         // bf16: transpose through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
         foreach_acc(acc, lane, [&](int row, int col, int, float v) {
+            if constexpr (EPI == EPI_BNACT) {
+                const int n = n0 + wcol0 + col < p.N ? n0 + wcol0 + col : p.N - 1;
+                v = silu_f(v * p.scale[n] + p.shift[n]);
+            }
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
         __syncthreads();
@@ -710,7 +717,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         };
         // bf16 tile through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
-        foreach([&](int row, int col, int, float v) { *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v; });
+        foreach([&](int row, int col, int, float v) {
+            if constexpr (EPI == EPI_BNACT) v = silu_f(v * p.scale[n0 + col] + p.shift[n0 + col]);
+            *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
+        });
         __syncthreads();
         constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
         bf16_t* out = (bf16_t*)p.out;
@@ -958,6 +968,22 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_
     }
 }
 
+// zero border of a halo NHWC buffer [B][H+2p][W+2p][C] (16-byte pieces): one block per padded row
+__global__ __launch_bounds__(256) void halo_border_zero_kernel(uint4* __restrict__ z, int H, int W, int cpp, int pad) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int yp = blockIdx.x % Hp;
+    uint4* row = z + (int64_t)blockIdx.x * Wp * cpp;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (yp < pad || yp >= H + pad) {
+        for (int i = threadIdx.x; i < Wp * cpp; i += 256) row[i] = zero;
+    } else {
+        for (int i = threadIdx.x; i < 2 * pad * cpp; i += 256) {
+            const int side = i / (pad * cpp), j = i - side * pad * cpp;
+            row[(side ? (W + pad) * cpp : 0) + j] = zero;
+        }
+    }
+}
+
 // Stride-2 dgrad of thin layers: the two output x-parities of a row are produced together as N' = 2*Cin columns (the
 // pixel pair (2j, 2j+1) is contiguous in NHWC), from "virtual taps" v = ky*2 + dxo whose [2*Cin][Cout] matrices hold
 // kx=1 | kx=2 for dxo=0 and zeros | kx=0 for dxo=1.  2 launches instead of 4, full-line stores, 4/3 of the MACs.
@@ -1098,6 +1124,33 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
     p.out = y;
     p.stats = stats_partial;
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
+}
+
+int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
+                       const void* residual, void* z, int32_t z_pad, void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_conv_fwd_bnact");
+    if (rc) return rc;
+    if (!x || !w_fwd || !scale || !shift || !z) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bnact: null pointer");
+    if (d->Cout % 8 || z_pad < 0) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bnact: Cout %d not a multiple of 8 or bad z_pad", d->Cout);
+    const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
+    p.in = x;
+    p.wt = w_fwd;
+    p.out = z;
+    p.scale = scale;
+    p.shift = shift;
+    p.addend = residual;          // same halo geometry as z
+    p.out_dense = 0;
+    p.out_row = OW + 2 * z_pad;
+    p.out_img = (OH + 2 * z_pad) * p.out_row;
+    p.osy = p.osx = 1;
+    p.ooy = p.oox = z_pad;
+    rc = launch_igemm<EPI_BNACT>(d->dtype, p, (hipStream_t)stream);
+    if (rc || z_pad == 0) return rc;
+    const int cpp = d->Cout * (d->dtype == FVA_BF16 ? 2 : 4) / 16;
+    hipLaunchKernelGGL(halo_border_zero_kernel, dim3(d->B * (OH + 2 * z_pad)), dim3(256), 0, (hipStream_t)stream, (uint4*)z, OH, OW, cpp, z_pad);
+    FVA_LAUNCH_CHECK("halo_border_zero_kernel");
+    return FVA_OK;
 }
 
 int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream) {

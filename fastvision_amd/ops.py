@@ -246,10 +246,18 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     M = B * OH * OW
     dev = x.device
     wf, wd = packed_weights(weight, d, dtype)
-    y = torch.empty((M, Cout), dtype=dtype, device=dev)
     scale = torch.empty(Cout, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mean = rstd = None
+    if not training and not need_ctx and (residual is None or residual[1] == 1):
+        # inference: running statistics fold into a per-channel affine, and affine + SiLU (+ residual) run in the conv
+        # epilogue -- one pass over the output instead of conv-out, apply-in, apply-out
+        _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
+        zbuf, z = halo_alloc(B, Cout, OH, OW, dtype, dev, 1)
+        _lib.call('fva_conv_fwd_bnact', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(scale), _p(shift),
+                  C.c_void_p(residual[0] if residual is not None else 0), _p(zbuf), 1, _stream())
+        return z, None
+    y = torch.empty((M, Cout), dtype=dtype, device=dev)
     if training:
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
         stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
@@ -319,7 +327,7 @@ class ConvBNSiLUFn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, bn, training, stride, dtype):
         require_gpu(x, 'ConvBlock')
         keep, x_ptr, x_pad = to_halo(x, dtype, weight.shape[2] // 2)
-        need = any(ctx.needs_input_grad)
+        need = _GRAD_ON[0] and any(ctx.needs_input_grad)
         z, s = conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, need_ctx=need)
         if s is not None:
             s.keep = keep
@@ -406,7 +414,7 @@ class ResidualFn(torch.autograd.Function):
     def forward(ctx, x, w1, g1, b1, bn1, w2, g2, b2, bn2, training, dtype):
         require_gpu(x, 'ResidualBlock')
         keep, x_ptr, x_pad = to_halo(x, dtype, 1)
-        need = any(ctx.needs_input_grad)
+        need = _GRAD_ON[0] and any(ctx.needs_input_grad)
         z1, s1 = conv_block_fwd(x, x_ptr, x_pad, w1, g1, b1, bn1, training, 1, dtype, need_ctx=need)
         z1_ptr, z1_pad = halo_info(z1, dtype)
         z2, s2 = conv_block_fwd(z1, z1_ptr, z1_pad, w2, g2, b2, bn2, training, 1, dtype, residual=(x_ptr, x_pad), need_ctx=need)
@@ -506,9 +514,15 @@ class HeadFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ thin functional API
+# autograd.Function.forward always runs with grad mode off, and ctx.needs_input_grad ignores torch.no_grad(): the wrappers
+# below note the caller's grad mode here so that inference (no_grad) takes the context-free fused path
+_GRAD_ON = [True]
+
+
 def conv_bn_silu(x, conv, bn, stride=None, dtype=None):
     dtype = dtype or get_compute_dtype()
     stride = conv.stride[0] if stride is None else stride
+    _GRAD_ON[0] = torch.is_grad_enabled()
     return ConvBNSiLUFn.apply(x, conv.weight, bn.weight, bn.bias, _BNState(bn), bn.training, stride, dtype)
 
 
@@ -519,6 +533,7 @@ def stem(images, conv, bn, dtype=None):
 
 def residual(x, cb1, cb2, dtype=None):
     dtype = dtype or get_compute_dtype()
+    _GRAD_ON[0] = torch.is_grad_enabled()
     return ResidualFn.apply(x, cb1.conv.weight, cb1.bn.weight, cb1.bn.bias, _BNState(cb1.bn),
                             cb2.conv.weight, cb2.bn.weight, cb2.bn.bias, _BNState(cb2.bn), cb1.bn.training, dtype)
 

@@ -88,6 +88,13 @@ int64_t fva_conv_streamk_timeouts(void);
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
  * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
+/* Inference form: eval-mode BatchNorm folded into a per-channel affine and SiLU applied in the convolution's epilogue,
+ * z = SiLU(conv(x) * scale[c] + shift[c]) (+ residual), written straight into the halo buffer z [B][OH+2p][OW+2p][Cout]
+ * (interior by the MFMA kernel, zero border by a small second launch).  residual (optional) has z's geometry.
+ * Replaces conv + bn (running statistics) + SiLU (+ add) of ConvBlock / ResidualBlock in eval mode
+ * (classfication/models/darknet53.py:28-31,58-62) with one pass over the output instead of three. */
+int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
+                       const void* residual, void* z, int32_t z_pad, void* stream);
 int32_t fva_conv_stat_blocks(const fva_conv_desc* d);
 
 /* dx[B][H][W][Cin] (dense, dtype) = conv_transpose(dy, w) (+ addend).  dy is halo NHWC with border d->dy_pad.

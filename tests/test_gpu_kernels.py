@@ -318,3 +318,39 @@ def test_wgrad_8phase_kernel_matches_128_tile_kernel(tmp_path):
         outs.append(out)
     r = subprocess.run([sys.executable, tool, 'compare'] + outs, capture_output=True, text=True)
     assert r.returncode == 0 and 'all within' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('key', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 32, 64, 24, 3, 2), (2, 128, 256, 20, 3, 1), (3, 64, 32, 18, 1, 1), (32, 256, 512, 40, 3, 1)])
+def test_conv_fwd_bnact_equals_conv_then_apply(key, shape):
+    """the inference epilogue (affine + SiLU + residual inside the conv kernel, border by a second launch) against the
+    two-kernel path conv -> bn_silu_apply: fp32 to 1e-5, bf16 to the rounding of the unfused path's bf16 conv output"""
+    from fastvision_amd import _lib, ops
+    lib = _lib.load()
+    B, Cin, Cout, H, k, s = shape
+    dtype = torch.float32 if key == 'f32' else torch.bfloat16
+    if key == 'f32' and B == 32:
+        pytest.skip('large case is for the bf16 8-phase kernel')
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev()).to(dtype)
+    x[:, 0], x[:, -1], x[:, :, 0], x[:, :, -1] = 0, 0, 0, 0
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev())
+    OH = (H - 1) // s + 1
+    d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, k, s, 1, 1)
+    wf, _ = ops.packed_weights(w, d, dtype, cache=False)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev())
+    shift = torch.randn(Cout, generator=g).to(dev())
+    res = torch.randn(B, OH + 2, OH + 2, Cout, generator=g).to(dev()).to(dtype)
+    st = ops._stream()
+    y = torch.empty(B * OH * OH, Cout, dtype=dtype, device=dev())
+    _lib.call('fva_conv_fwd', C.byref(d), ops._p(x), ops._p(wf), ops._p(y), C.c_void_p(0), st)
+    for residual in (None, res):
+        ref = torch.full((B, OH + 2, OH + 2, Cout), float('nan'), dtype=dtype, device=dev())
+        _lib.call('fva_bn_silu_apply', ops._code(dtype), ops._p(y), ops._p(scale), ops._p(shift), ops._p(residual), 1, ops._p(ref), 1,
+                  B, OH, OH, Cout, st)
+        got = torch.full((B, OH + 2, OH + 2, Cout), float('nan'), dtype=dtype, device=dev())
+        _lib.call('fva_conv_fwd_bnact', C.byref(d), ops._p(x), ops._p(wf), ops._p(scale), ops._p(shift), ops._p(residual), ops._p(got), 1, st)
+        assert torch.isfinite(got).all()
+        assert (got[:, 0] == 0).all() and (got[:, -1] == 0).all() and (got[:, :, 0] == 0).all() and (got[:, :, -1] == 0).all()
+        tol = 1e-5 if key == 'f32' else 2e-2
+        assert rel_err(got.float(), ref.float()) < tol, (key, shape, residual is not None, rel_err(got.float(), ref.float()))
