@@ -55,12 +55,18 @@ def main():
         dec_ms, _ = timed(lambda: yolo_decode(list(head_out), m._anchor_lists, m.backbone_strides_per_level), a.steps)
         nms_ms, dets = timed(lambda: non_max_suppression_images(results, 0.25, 0.45, 300), a.steps)
         all_ms, _ = timed(lambda: non_max_suppression_images(m(images)[1], 0.25, 0.45, 300), a.steps)
+        from fastvision_amd.graphs import graphed_eval
+        gm = graphed_eval(m, images)
+        gfwd_ms, (ghead, gres) = timed(lambda: gm(images), a.steps)
+        assert torch.equal(gres, results)
+        gall_ms, _ = timed(lambda: non_max_suppression_images(gm(images)[1], 0.25, 0.45, 300), a.steps)
     cand = (results[..., 4] > 0.25).sum(1).float()
     out = {'workload': f'YOLOv3 eval {a.batch}x3x{a.size}x{a.size} bf16: forward + decode + NMS(0.25, 0.45, 300)', 'objectness_bias': a.bias, 'candidate_fraction_target': a.cand_frac,
            'candidates_per_image_mean': float(cand.mean()), 'candidates_per_image_max': float(cand.max()),
            'detections_per_image_mean': sum(len(d[0]) for d in dets) / a.batch,
            'forward_incl_decode_ms': round(fwd_ms, 3), 'decode_ms': round(dec_ms, 3), 'nms_ms': round(nms_ms, 3),
-           'total_ms': round(all_ms, 3), 'images_per_sec': round(a.batch / all_ms * 1e3, 1)}
+           'total_ms': round(all_ms, 3), 'images_per_sec': round(a.batch / all_ms * 1e3, 1),
+           'hip_graph': {'forward_incl_decode_ms': round(gfwd_ms, 3), 'total_ms': round(gall_ms, 3), 'images_per_sec': round(a.batch / gall_ms * 1e3, 1)}}
     if a.cpu_images:
         from oracle import detect as D
         res_h = results[:a.cpu_images].float().cpu()
