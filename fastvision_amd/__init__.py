@@ -11,7 +11,8 @@ The package mirrors the reference's Python surface for that path and nothing els
     fastvision_amd.utils.Fit, .utils.sheduler, .utils.checkpoints   (utils/fit.py step contract; f-1 helpers)
     fastvision_amd.demos.yolov3_u.{models,utils,cfg}       (demos/yolov3_u: YoloV3, ComputeLoss, Fit/_Train, nms, postProcess)
 
-plus ``FusedAdam`` and ``parallel`` (one process per GPU, RCCL gradient all-reduce).  All device arithmetic
+plus ``FusedAdam``, ``parallel`` (one process per GPU, RCCL gradient all-reduce) and ``graphs`` (HIP-graph replay of the
+shape-static inference forward).  All device arithmetic
 runs in hand-written HIP kernels behind the C ABI of include/fastvision_amd.h (csrc/); importing the package
 is cheap, the shared library is loaded on first use and its absence is an error (no CPU fallback).
 """
