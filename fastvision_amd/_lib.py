@@ -54,6 +54,8 @@ _H = C.POINTER(HeadLevel)
 PROTOTYPES = {
     'fva_last_error': (C.c_char_p, []),
     'fva_version': (_I, []),
+    'fva_profile_start': (_I, [_I]),
+    'fva_profile_stop': (_I, [_P, _P, _P, _I]),
     'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
     'fva_conv_packed_elems': (_L, [_D, _I]),
     'fva_conv_pack_weights_multi': (_I, [_P, _I, _L, _P]),
@@ -100,7 +102,7 @@ PROTOTYPES = {
     'fva_nms_select_workspace': (_L, [_I, _I]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_last_error', 'fva_version', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

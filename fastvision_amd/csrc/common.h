@@ -91,3 +91,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- in-library timing of the MFMA convolution entry points (fva_profile_start / fva_profile_stop) ---------------------
+// A span records one HIP event on the launch stream when it is made and one when it goes out of scope; disabled = no-op.
+struct FvaProfileSpan {
+    int slot;
+    hipStream_t stream;
+    FvaProfileSpan(int cls, double flop, hipStream_t s);
+    ~FvaProfileSpan();
+};

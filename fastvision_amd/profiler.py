@@ -1,5 +1,9 @@
 """Live per-kernel timing with HIP events recorded on the stream each call is launched on (its `stream` argument).
 
+Two implementations with one interface: ``KernelTimer`` arms the spans built into the library (fva_profile_start / _stop:
+no per-call host work, which matters when the host has little headroom over the GPU), ``PyKernelTimer`` brackets the calls
+from Python with torch events and also keeps each call's layer shape (``by_shape``, for tuning).
+
     with KernelTimer() as kt:
         ... training steps ...
     kt.summary()  ->  {class: {'launches', 'ms_total', 'ms_avg', 'flop_per_launch', 'tflops'}}
@@ -38,9 +42,45 @@ class _Span:
         self.rec[2].record(self.stream)
 
 
-class KernelTimer:
+class _Counter:
+    """Tracer that only counts the bracketed calls (used on a warm-up step to size a KernelTimer's event pool)."""
+
     def __init__(self):
+        self.calls = 0
+
+    def _trace(self, name, args):
+        if name in CONV_CALLS:
+            self.calls += 1
+        return None
+
+    def __enter__(self):
+        self.prev = _lib.tracer
+        _lib.tracer = self._trace
+        return self
+
+    def __exit__(self, *a):
+        _lib.tracer = self.prev
+
+
+def count_calls():
+    return _Counter()
+
+
+class PyKernelTimer:
+    def __init__(self, pool=0):
+        """pool: number of bracketed calls expected.  Their HIP events are created (and recorded once, which is what makes
+        the runtime allocate them) HERE, outside the region being timed: creating thousands of timing events costs a kernel-
+        driver call each, and those calls can stall for seconds while the driver is still tearing down a previous GPU
+        process -- it must not be charged to the step."""
         self.records = []
+        self.pool = []
+        for _ in range(pool):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            self.pool.append((e0, e1))
+        if pool:
+            torch.cuda.synchronize()
 
     def _trace(self, name, args):
         cls = CONV_CALLS.get(name)
@@ -49,8 +89,8 @@ class KernelTimer:
         d = args[0]._obj
         oh, ow = (d.H - 1) // d.stride + 1, (d.W - 1) // d.stride + 1
         flop = 2.0 * d.B * oh * ow * d.Cout * d.Cin * d.ksize * d.ksize
-        rec = (cls, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flop,
-               (d.Cin, d.Cout, d.ksize, d.stride, oh))
+        e0, e1 = self.pool.pop() if self.pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        rec = (cls, e0, e1, flop, (d.Cin, d.Cout, d.ksize, d.stride, oh))
         self.records.append(rec)
         return _Span(rec, _stream_of(args[-1]))
 
@@ -86,3 +126,43 @@ class KernelTimer:
             s[1] += e0.elapsed_time(e1)
             s[2] += flop
         return {k: (v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0) for k, v in out.items()}
+
+
+class KernelTimer:
+    """Spans recorded inside the library around fva_conv_fwd / fva_head_fwd / fva_conv_fwd_bnact (class conv_fwd),
+    fva_conv_dgrad (conv_dgrad) and fva_conv_wgrad incl. its reduce (conv_wgrad).  ``pool`` = number of calls expected
+    while armed (more are simply not timed); the events are created in __enter__, before anything the caller times."""
+    CLASSES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad')
+
+    def __init__(self, pool=4096):
+        self.pool = int(pool)
+        self.spans = None
+
+    def __enter__(self):
+        _lib.call('fva_profile_start', self.pool)
+        return self
+
+    def __exit__(self, *a):
+        self._collect()
+
+    def _collect(self):
+        if self.spans is None:
+            import ctypes as C
+            n = self.pool
+            cls, flop, ms = (C.c_int32 * n)(), (C.c_double * n)(), (C.c_float * n)()
+            got = _lib.load().fva_profile_stop(cls, flop, ms, n)
+            self.spans = [(self.CLASSES[cls[i]], flop[i], ms[i]) for i in range(got)]
+        return self.spans
+
+    def summary(self):
+        out = {}
+        for c, flop, ms in self._collect():
+            s = out.setdefault(c, {'launches': 0, 'ms_total': 0.0, 'flop_total': 0.0})
+            s['launches'] += 1
+            s['ms_total'] += ms
+            s['flop_total'] += flop
+        for s in out.values():
+            s['ms_avg'] = s['ms_total'] / s['launches']
+            s['flop_per_launch'] = s['flop_total'] / s['launches']
+            s['tflops'] = s['flop_total'] / (s['ms_total'] * 1e-3) / 1e12 if s['ms_total'] > 0 else 0.0
+        return out

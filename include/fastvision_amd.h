@@ -42,6 +42,13 @@ typedef enum {
 const char* fva_last_error(void);
 int fva_version(void);
 
+/* Live timing of the MFMA convolution entry points with HIP events on their launch stream, taken inside the library (no
+ * per-call host work in the caller).  fva_profile_start(max_spans) creates the events -- call it OUTSIDE the region being
+ * timed -- and arms the spans; fva_profile_stop() synchronises the device, disarms and returns the number of spans with
+ * cls (0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce), algorithmic FLOPs and elapsed milliseconds of each. */
+int fva_profile_start(int32_t max_spans);
+int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32_t cap);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution (no bias), implicit GEMM on MFMA.  Replaces nn.Conv2d as used by ConvBlock3x3 /
  * ConvBlock1x1 (classfication/models/darknet53.py:5-9,22-44; detection/neck/yolov3neck.py:5-9,22-44;
