@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn a rocprofv3 --kernel-trace --stats CSV into the per-kernel summary kept under profiles/.
-usage: tools/summarize_prof.py <kernel_stats.csv> <steps_profiled> [title]"""
+usage: tools/summarize_prof.py <kernel_stats.csv> <steps_profiled | 0> [title]
+steps 0 = count them: the optimizer kernel runs once per step (bench.py also steps while it settles, untimed)."""
 import csv
 import re
 import subprocess
@@ -21,6 +22,8 @@ def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     title = sys.argv[3] if len(sys.argv) > 3 else path
     rows = list(csv.DictReader(open(path)))
+    if steps == 0:
+        steps = max([int(r['Calls']) for r in rows if 'adam_kernel' in r['Name']] or [1])
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     print(f'# {title}\n')
     print(f'rocprofv3 --kernel-trace --stats; {steps} steps profiled (warm-up included); total kernel time '
