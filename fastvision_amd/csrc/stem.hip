@@ -4,6 +4,8 @@
 //
 // Replaces `conv0` of Darknet-53 (reference classfication/models/darknet53.py:73) forward and weight gradient
 // (the input image needs no gradient).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -180,21 +182,159 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     if (threadIdx.x == 0) dw[i] = accumulate ? dw[i] + red[0] : red[0];
 }
 
+// ---- MFMA forward (bf16) ---------------------------------------------------------------------------------------------
+// conv0 as D[co][pix] = sum_k W[co][k] * P[k][pix] on v_mfma_f32_16x16x32_bf16, K = 36 (3 rows x 3 columns x 4 channels,
+// the 4th channel zero) padded to 64.  The images are first packed to a zero-bordered bf16 NHWC4 buffer (8 bytes per pixel:
+// stem_pack_kernel), so that lane (pixel r, k-group g) gets its eight consecutive k -- two horizontally adjacent taps of four
+// channels -- by two 8-byte loads straight from global memory / L1 (no LDS: every patch byte is used by one wave only).
+// A wave walks TILES_PER_WAVE tiles of 16 consecutive pixels of one image row.  Per tile: 3 loads, 4 MFMAs (two 16-channel
+// halves x two k-steps), two 8-byte stores per lane; BatchNorm partial sums stay in registers until the end of the block.
+constexpr int STEM_TPW = 16;                       // tiles per wave
+constexpr int STEM_BLOCK_PIX = 4 * STEM_TPW * 16;  // 1024 pixels per block
+
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ img, uint2* __restrict__ out, int B, int Cin, int H,
+                                                        int W) {
+    const int Wp = W + 2, Hp = H + 2;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp), yp = (int)((i / Wp) % Hp), b = (int)(i / ((int64_t)Wp * Hp));
+        const int x = xp - 1, y = yp - 1;
+        bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const float* p = img + ((int64_t)b * Cin * H + y) * W + x;
+            for (int c = 0; c < Cin; ++c) v[c] = (bf16_t)p[(int64_t)c * H * W];
+        }
+        out[i] = __builtin_bit_cast(uint2, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const uint2* __restrict__ img4, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ y, float* __restrict__ stats, int Cin, int H, int W,
+                                                            int64_t M) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int Wp = W + 2;
+    // weight fragments: A[co = 16c + r][k = 32s + 8g + j], k = kh*12 + kw*4 + ci
+    bf16x8 wa[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * s + 8 * g + j;
+                const int kh = k / 12, kw = (k % 12) / 4, ci = k & 3;
+                float v = 0.f;
+                if (k < 36 && ci < Cin) v = w[(((16 * c + r) * Cin + ci) * 3 + kh) * 3 + kw];
+                wa[c][s][j] = (bf16_t)v;
+            }
+    // patch fragment: taps t = 2g, 2g + 1 (k-step 0) and t = 8 for g == 0 (k-step 1); tap t sits at (t / 3, t % 3)
+    const int ta = 2 * g, tb = 2 * g + 1;
+    const int offa = (ta / 3) * Wp + ta % 3, offb = (tb / 3) * Wp + tb % 3, offc = 2 * Wp + 2;
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[c][j] = s2[c][j] = 0.f;
+
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * STEM_TPW;
+    const int tiles_per_row = W / 16;
+#pragma unroll 2
+    for (int t = 0; t < STEM_TPW; ++t) {
+        const int64_t tile = tile0 + t;
+        const int64_t m0 = tile * 16;
+        if (m0 >= M) break;
+        const int64_t row = tile / tiles_per_row;            // b * H + y
+        const int x0 = (int)(tile - row * tiles_per_row) * 16;
+        const int b = (int)(row / H), yy = (int)(row - (int64_t)b * H);
+        const uint2* base = img4 + ((int64_t)b * (H + 2) + yy) * Wp + x0 + r;   // halo pixel of tap (0, 0)
+        const uint2 la = base[offa], lb = base[offb], lc = base[offc];
+        const bf16x8 p0 = __builtin_bit_cast(bf16x8, make_uint4(la.x, la.y, lb.x, lb.y));
+        const bf16x8 p1 = __builtin_bit_cast(bf16x8, g == 0 ? make_uint4(lc.x, lc.y, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u));
+        f32x4 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][0], p0, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][1], p1, acc[c], 0, 0, 0);
+        }
+        // D rows = channels 16c + 4g + j, column = pixel r: four consecutive channels per lane -> one 8-byte store
+        bf16_t* yo = y + (m0 + r) * 32 + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (bf16_t)acc[c][j];
+                s1[c][j] += acc[c][j];
+                s2[c][j] += acc[c][j] * acc[c][j];
+            }
+            *(bf16x4*)(yo + 16 * c) = o;
+        }
+    }
+    if (stats == nullptr) return;
+    // per-channel sums over the wave's pixels (lanes that share g), then over the four waves, one row per block
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[c][j] += __shfl_xor(s1[c][j], o);
+                s2[c][j] += __shfl_xor(s2[c][j], o);
+            }
+            if (r == 0) {
+                red[0][wv][16 * c + 4 * g + j] = s1[c][j];
+                red[1][wv][16 * c + 4 * g + j] = s2[c][j];
+            }
+        }
+    __syncthreads();
+    if (tid < 64) {
+        const int which = tid >> 5, ch = tid & 31;
+        stats[((int64_t)blockIdx.x * 2 + which) * 32 + ch] = (red[which][0][ch] + red[which][1][ch]) + (red[which][2][ch] + red[which][3][ch]);
+    }
+}
+
 constexpr int WGRAD_BLOCKS = 1024;
 
 }  // namespace
 
 extern "C" {
 
-int32_t fva_stem_stat_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, 256); }
+// the MFMA forward serves the bf16 path when an image row is a whole number of 16-pixel tiles
+static bool stem_mfma(int dtype, int W) {
+    static const bool on = [] { const char* e = getenv("FVA_STEM_MFMA"); return !e || atoi(e) != 0; }();
+    return on && dtype == FVA_BF16 && W % 16 == 0;
+}
 
-int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* stats, int B, int Cin, int H, int W, int Cout,
-                 void* stream) {
+int32_t fva_stem_stat_blocks(int dtype, int B, int H, int W) {
+    const int64_t M = (int64_t)B * H * W;
+    return stem_mfma(dtype, W) ? cdiv(M, STEM_BLOCK_PIX) : cdiv(M, 256);
+}
+
+int64_t fva_stem_fwd_workspace(int dtype, int B, int H, int W) {
+    return stem_mfma(dtype, W) ? (int64_t)B * (H + 2) * (W + 2) * 8 : 0;
+}
+
+int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* stats, void* workspace, int64_t workspace_bytes, int B,
+                 int Cin, int H, int W, int Cout, void* stream) {
     if (!img || !w || !y) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: null pointer");
     if (Cout != CO || Cin < 1 || Cin > 3) return fva_fail(FVA_ERR_ARG, "fva_stem_fwd: needs Cout==32, Cin<=3 (got %d, %d)", Cout, Cin);
     const int64_t M = (int64_t)B * H * W;
     const int grid = cdiv(M, 256);
     hipStream_t s = (hipStream_t)stream;
+    if (stem_mfma(dtype, W)) {
+        const int64_t need = fva_stem_fwd_workspace(dtype, B, H, W);
+        if (!workspace || workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_fwd: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
+        const int64_t hp = need / 8;
+        hipLaunchKernelGGL(stem_pack_kernel, dim3((int)((hp + 255) / 256 < 65536 ? (hp + 255) / 256 : 65536)), dim3(256), 0, s, img, (uint2*)workspace, B, Cin, H, W);
+        FVA_LAUNCH_CHECK("stem_pack_kernel");
+        hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(cdiv(M, STEM_BLOCK_PIX)), dim3(256), 0, s, (const uint2*)workspace, w, (bf16_t*)y, stats, Cin, H,
+                           W, M);
+        FVA_LAUNCH_CHECK("stem_fwd_mfma_kernel");
+        return FVA_OK;
+    }
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, w, (bf16_t*)y, stats, B, Cin, H, W, M);
     else if (dtype == FVA_F32)

@@ -369,15 +369,17 @@ class StemFn(torch.autograd.Function):
         scale = torch.empty(Cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
         mean = rstd = None
+        wsb = lib.fva_stem_fwd_workspace(code, B, H, W)           # bf16 NHWC4 copy of the images for the MFMA kernel
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         if training:
-            nblk = lib.fva_stem_stat_blocks(B, H, W)
+            nblk = lib.fva_stem_stat_blocks(code, B, H, W)
             stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
-            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), _p(stats), B, Cin, H, W, Cout, _stream())
+            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), _p(stats), _p(ws), wsb, B, Cin, H, W, Cout, _stream())
             mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
             _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
                       bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
         else:
-            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), C.c_void_p(0), B, Cin, H, W, Cout, _stream())
+            _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), C.c_void_p(0), _p(ws), wsb, B, Cin, H, W, Cout, _stream())
             _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
         zbuf, z = halo_alloc(B, Cout, H, W, dtype, dev, 1)
         _lib.call('fva_bn_silu_apply', code, _p(y), _p(scale), _p(shift), C.c_void_p(0), 0, _p(zbuf), 1, B, H, W, Cout, _stream())

@@ -114,11 +114,14 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d);
 
-/* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 3, Cout == 32 (darknet53.py:73 `conv0`), direct kernel.
- * y dense [B*H*W][Cout] dtype + BN partial stats;  wgrad from dy dense [B*H*W][Cout] (pad 0). */
+/* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 3, Cout == 32 (darknet53.py:73 `conv0`).
+ * y dense [B*H*W][Cout] dtype + BN partial stats;  wgrad from dy dense [B*H*W][Cout] (pad 0).
+ * bf16 with W a multiple of 16 runs on MFMA from a bf16 NHWC4 copy of the images that the call builds in `workspace`
+ * (fva_stem_fwd_workspace() bytes; 0 for the other cases, which use the exact fp32 direct kernel). */
 int fva_stem_fwd(int dtype, const float* images_nchw, const float* w_oihw, void* y, float* stats_partial,
-                 int B, int Cin, int H, int W, int Cout, void* stream);
-int32_t fva_stem_stat_blocks(int B, int H, int W);
+                 void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
+int64_t fva_stem_fwd_workspace(int dtype, int B, int H, int W);
+int32_t fva_stem_stat_blocks(int dtype, int B, int H, int W);
 int fva_stem_wgrad(int dtype, const float* images_nchw, const void* dy, float* dw_oihw, int accumulate,
                    void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
 int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
