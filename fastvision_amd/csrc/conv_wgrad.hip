@@ -38,6 +38,7 @@ struct WgradParams {
     int tap_pix[9];
     int ntn, ntc, ksplit, mchunk;
     int tpt, ngroups;  // taps packed side by side in one column tile (thin layers: C < tile), tap groups
+    int x_pix_bytes;   // bytes between consecutive pixels of x; 0 = C * sizeof(T) (the stem reads overlapping 4-pixel windows)
 };
 
 // ds_read_b64_tr_b16 as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever an LDS-DMA
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int lrow = lane >> 4;
     const int f = IS_BF16 ? ((lrow << 2) | w) : 0;  // swizzle of this lane's rows: ((R&3)<<2)|((R>>2)&3)
     const int chunk = (lane & 15) ^ f;
-    const uint32_t dy_pixb = (uint32_t)p.dy_pitch * (uint32_t)sizeof(T), x_pixb = (uint32_t)p.C * (uint32_t)sizeof(T);
+    const uint32_t dy_pixb = (uint32_t)p.dy_pitch * (uint32_t)sizeof(T);
+    const uint32_t x_pixb = p.x_pix_bytes ? (uint32_t)p.x_pix_bytes : (uint32_t)p.C * (uint32_t)sizeof(T);
     const bool a_ok = n0 + chunk * EPC < p.N;  // columns beyond N / C feed only unused outputs: point them
     const uint32_t a_colb = (uint32_t)(a_ok ? n0 + chunk * EPC : 0) * (uint32_t)sizeof(T);  // at column 0 (in bounds)
     // B column -> (tap, channel): with tpt > 1 the tile holds tpt taps of all C channels side by side
@@ -659,5 +661,58 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     FVA_LAUNCH_CHECK("wgrad_reduce_kernel");
     return FVA_OK;
 }
+
+/* Stem weight gradient on MFMA: conv0 (3 x 3, Cin <= 3) seen as a 3 x 1 convolution over "pixels" of 16 channels -- the four
+ * horizontally adjacent pixels x-1 .. x+2 of the bf16 NHWC4 image fva_stem_fwd packs (8 bytes per pixel, overlapping windows:
+ * x_pix_bytes = 8) -- so that the generic kernel applies: N = 32, C = 16, three vertical taps packed into one column tile.
+ * dw_raw[32][16][3] = [co][kw*4 + ci][kh]; the caller keeps kw < 3, ci < Cin. */
+int fva_stem_wgrad_mfma(const void* img4, const void* dy_halo, float* dw_raw, void* workspace, int64_t workspace_bytes, int B, int H,
+                        int W, void* stream) {
+    if (!img4 || !dy_halo || !dw_raw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad_mfma: null pointer");
+    const int64_t M = (int64_t)B * H * W;
+    if (M >= (1ll << 31) || (int64_t)B * (H + 2) * (W + 2) * 64 >= (1ll << 32)) return fva_fail(FVA_ERR_ARG, "fva_stem_wgrad_mfma: too large");
+    const int ksplit_max = 512;
+    int mchunk = cdiv(cdiv(M, ksplit_max), 64) * 64;
+    const int ksplit = cdiv(M, mchunk);
+    const int64_t need = (int64_t)ksplit * 3 * 32 * 16 * 4;
+    if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_wgrad_mfma: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
+    WgradParams p = WgradParams();
+    p.x = img4;
+    p.dy = dy_halo;
+    p.slab = (float*)workspace;
+    p.M = (int)M;
+    p.N = 32;
+    p.C = 16;
+    p.x_pix_bytes = 8;
+    p.OW = W;
+    p.OHW = H * W;
+    p.div_ow = make_fastdiv(p.OW);
+    p.div_ohw = make_fastdiv(p.OHW);
+    p.x_row = W + 2;
+    p.x_img = (H + 2) * p.x_row;
+    p.sy = p.sx = 1;
+    p.x_y0 = p.x_x0 = 0;
+    p.dy_row = W + 2;
+    p.dy_img = (H + 2) * p.dy_row;
+    p.dy_pad = 1;
+    p.dy_pitch = 32;
+    p.dy_zero_off = 0;
+    p.ntaps = 3;
+    for (int kh = 0; kh < 3; ++kh) p.tap_pix[kh] = kh * p.x_row;
+    p.ntn = p.ntc = 1;
+    p.ksplit = ksplit;
+    p.mchunk = mchunk;
+    p.tpt = 8;
+    p.ngroups = 1;
+    FvaProfileSpan span(2, 2.0 * M * 32.0 * 27.0, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(ksplit), dim3(256), 2 * 2 * 64 * 256, s, p);
+    FVA_LAUNCH_CHECK("wgrad_kernel");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((32 * 16 + 63) / 64), dim3(256), 0, s, (const float*)workspace, dw_raw, 32, 16, 3, ksplit, 0);
+    FVA_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return FVA_OK;
+}
+
+int64_t fva_stem_wgrad_mfma_workspace(void) { return 512ll * 3 * 32 * 16 * 4; }
 
 }  // extern "C"

@@ -314,7 +314,7 @@ int32_t fva_stem_stat_blocks(int dtype, int B, int H, int W) {
 }
 
 int64_t fva_stem_fwd_workspace(int dtype, int B, int H, int W) {
-    return stem_mfma(dtype, W) ? (int64_t)B * (H + 2) * (W + 2) * 8 : 0;
+    return stem_mfma(dtype, W) ? (int64_t)B * (H + 2) * (W + 2) * 8 + 64 : 0;   // + slack: the wgrad's 4-pixel windows read one pixel past a row
 }
 
 int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* stats, void* workspace, int64_t workspace_bytes, int B,
@@ -327,7 +327,7 @@ int fva_stem_fwd(int dtype, const float* img, const float* w, void* y, float* st
     if (stem_mfma(dtype, W)) {
         const int64_t need = fva_stem_fwd_workspace(dtype, B, H, W);
         if (!workspace || workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_fwd: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
-        const int64_t hp = need / 8;
+        const int64_t hp = (need - 64) / 8;
         hipLaunchKernelGGL(stem_pack_kernel, dim3((int)((hp + 255) / 256 < 65536 ? (hp + 255) / 256 : 65536)), dim3(256), 0, s, img, (uint2*)workspace, B, Cin, H, W);
         FVA_LAUNCH_CHECK("stem_pack_kernel");
         hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(cdiv(M, STEM_BLOCK_PIX)), dim3(256), 0, s, (const uint2*)workspace, w, (bf16_t*)y, stats, Cin, H,

@@ -8,6 +8,7 @@ strided *view* of a halo NHWC buffer [B,H+2,W+2,C] (zero border).  Modules hand 
 zero-copy; foreign tensors (any strides, fp32/bf16) are packed on entry.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -384,6 +385,7 @@ class StemFn(torch.autograd.Function):
         zbuf, z = halo_alloc(B, Cout, H, W, dtype, dev, 1)
         _lib.call('fva_bn_silu_apply', code, _p(y), _p(scale), _p(shift), C.c_void_p(0), 0, _p(zbuf), 1, B, H, W, Cout, _stream())
         ctx.saved = (img, y, scale, shift, mean, rstd, gamma, dtype, training, tuple(weight.shape))
+        ctx.img4 = ws                     # bf16 NHWC4 copy of the images (MFMA path): the weight gradient reads it again
         return z
 
     @staticmethod
@@ -406,6 +408,17 @@ class StemFn(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_bwd_finalize', _p(part), nb, M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+        if ctx.img4 is not None and os.environ.get('FVA_STEM_WGRAD_MFMA', '1') != '0':
+            # MFMA path: dY as a halo buffer, conv0 seen as 3 vertical taps over 4-pixel windows of the NHWC4 image
+            dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
+            _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
+                      _p(dy), 1, B, H, W, Cout, _stream())
+            raw = torch.empty((Cout, 4, 4, 3), dtype=torch.float32, device=dev)        # [co][kw][ci][kh]
+            wsb = lib.fva_stem_wgrad_mfma_workspace()
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.call('fva_stem_wgrad_mfma', _p(ctx.img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
+            dw = raw[:, :3, :Cin, :].permute(0, 2, 3, 1).contiguous()
+            return None, dw, dgamma, dbeta, None, None, None
         dy = torch.empty((M, Cout), dtype=dtype, device=dev)
         _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
                   _p(dy), 0, B, H, W, Cout, _stream())

@@ -125,6 +125,11 @@ int32_t fva_stem_stat_blocks(int dtype, int B, int H, int W);
 int fva_stem_wgrad(int dtype, const float* images_nchw, const void* dy, float* dw_oihw, int accumulate,
                    void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
 int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
+/* bf16 alternative on the MFMA weight-gradient kernel, from the NHWC4 image copy that fva_stem_fwd left in its workspace and
+ * a halo dY [B][H+2][W+2][32]: dw_raw [32][16][3] fp32 = [co][kw*4 + ci][kh] (the caller keeps kw < 3, ci < Cin). */
+int fva_stem_wgrad_mfma(const void* images_nhwc4, const void* dy_halo, float* dw_raw, void* workspace, int64_t workspace_bytes,
+                        int B, int H, int W, void* stream);
+int64_t fva_stem_wgrad_mfma_workspace(void);
 
 /* Head: biased 1x1 conv to N = A*(5+C) channels (detection/head/yolov3head.py:50,60;
  * demos/yolov3_u/models/yolov3.py:119-135).  Output fp32, dense [B*H*W][N] (pixel-major, N contiguous):

@@ -361,3 +361,29 @@ def test_conv_fwd_bnact_equals_conv_then_apply(key, shape):
         assert (got[:, 0] == 0).all() and (got[:, -1] == 0).all() and (got[:, :, 0] == 0).all() and (got[:, :, -1] == 0).all()
         tol = 1e-5 if key == 'f32' else 2e-2
         assert rel_err(got.float(), ref.float()) < tol, (key, shape, residual is not None, rel_err(got.float(), ref.float()))
+
+
+def test_stem_wgrad_mfma_matches_direct_kernel():
+    """conv0's weight gradient through the MFMA wgrad kernel (3 vertical taps over 4-pixel windows of the packed NHWC4 image)
+    against the register-blocked direct kernel, on the bf16-rounded operands both see"""
+    from fastvision_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 3, 40, 64
+    img = torch.rand(B, 3, H, W, generator=g).to(dev())
+    w = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).to(dev())
+    gy = torch.randn(B, H, W, 32, generator=g).to(dev()).to(torch.bfloat16)
+    y = torch.empty(B * H * W, 32, dtype=torch.bfloat16, device=dev())
+    wsb = lib.fva_stem_fwd_workspace(1, B, H, W)
+    img4 = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    st = ops._stream()
+    _lib.call('fva_stem_fwd', 1, ops._p(img), ops._p(w), ops._p(y), C.c_void_p(0), ops._p(img4), wsb, B, 3, H, W, 32, st)
+    dyh = torch.zeros(B, H + 2, W + 2, 32, dtype=torch.bfloat16, device=dev())
+    dyh[:, 1:-1, 1:-1] = gy
+    raw = torch.full((32, 4, 4, 3), float('nan'), device=dev())
+    wb = lib.fva_stem_wgrad_mfma_workspace()
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev())
+    _lib.call('fva_stem_wgrad_mfma', ops._p(img4), ops._p(dyh), ops._p(raw), ops._p(ws), wb, B, H, W, st)
+    got = raw[:, :3, :3, :].permute(0, 2, 3, 1)
+    want = torch.nn.grad.conv2d_weight(img.bfloat16().float(), w.shape, gy.float().permute(0, 3, 1, 2), padding=1)
+    assert rel_err(got, want) < 1e-4, rel_err(got, want)
