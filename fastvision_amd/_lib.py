@@ -71,10 +71,13 @@ PROTOTYPES = {
     'fva_stem_fwd': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     'fva_stem_fwd_workspace': (_L, [_I, _I, _I, _I]),
     'fva_stem_stat_blocks': (_I, [_I, _I, _I, _I]),
+    'fva_stem_fused_blocks': (_I, [_I, _I, _I]),
     'fva_stem_wgrad': (_I, [_I, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
     'fva_stem_wgrad_workspace': (_L, [_I, _I, _I, _I, _I]),
     'fva_stem_wgrad_mfma': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'fva_stem_wgrad_mfma_workspace': (_L, []),
+    'fva_stem_pack': (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    'fva_stem_fused': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'fva_head_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_head_bwd_prepare': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'fva_bn_finalize': (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
@@ -106,7 +109,7 @@ PROTOTYPES = {
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
 UNCHECKED = {'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
-             'fva_stem_stat_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
+             'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 
 _lib = None

@@ -11,10 +11,6 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_grad(float u) {
-    const float s = sigm_fast(u);
-    return s * (1.f + u * (1.f - s));
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // forward statistics -> coefficients.  Block = 16 channels x 64 partial-row groups (1024 threads): the partial

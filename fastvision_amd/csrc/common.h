@@ -83,6 +83,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // competes with the memory pipeline in the HBM-bound BatchNorm / SiLU kernels and in fused conv epilogues
 __device__ __forceinline__ float sigm_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
 __device__ __forceinline__ float silu_f(float u) { return u * sigm_fast(u); }
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = sigm_fast(u);
+    return s * (1.f + u * (1.f - s));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -91,6 +95,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// zero border of a halo NHWC buffer [B][H+2p][W+2p][C] given in 16-byte pieces per pixel (errors.hip)
+int fva_zero_halo_border(void* z, int B, int H, int W, int chunks_per_pixel, int pad, hipStream_t stream);
 
 // ---- in-library timing of the MFMA convolution entry points (fva_profile_start / fva_profile_stop) ---------------------
 // A span records one HIP event on the launch stream when it is made and one when it goes out of scope; disabled = no-op.

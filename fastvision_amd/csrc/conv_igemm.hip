@@ -968,22 +968,6 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_
     }
 }
 
-// zero border of a halo NHWC buffer [B][H+2p][W+2p][C] (16-byte pieces): one block per padded row
-__global__ __launch_bounds__(256) void halo_border_zero_kernel(uint4* __restrict__ z, int H, int W, int cpp, int pad) {
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const int yp = blockIdx.x % Hp;
-    uint4* row = z + (int64_t)blockIdx.x * Wp * cpp;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
-    if (yp < pad || yp >= H + pad) {
-        for (int i = threadIdx.x; i < Wp * cpp; i += 256) row[i] = zero;
-    } else {
-        for (int i = threadIdx.x; i < 2 * pad * cpp; i += 256) {
-            const int side = i / (pad * cpp), j = i - side * pad * cpp;
-            row[(side ? (W + pad) * cpp : 0) + j] = zero;
-        }
-    }
-}
-
 // Stride-2 dgrad of thin layers: the two output x-parities of a row are produced together as N' = 2*Cin columns (the
 // pixel pair (2j, 2j+1) is contiguous in NHWC), from "virtual taps" v = ky*2 + dxo whose [2*Cin][Cout] matrices hold
 // kx=1 | kx=2 for dxo=0 and zeros | kx=0 for dxo=1.  2 launches instead of 4, full-line stores, 4/3 of the MACs.
@@ -1149,10 +1133,7 @@ int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd,
     FvaProfileSpan span(0, 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     rc = launch_igemm<EPI_BNACT>(d->dtype, p, (hipStream_t)stream);
     if (rc || z_pad == 0) return rc;
-    const int cpp = d->Cout * (d->dtype == FVA_BF16 ? 2 : 4) / 16;
-    hipLaunchKernelGGL(halo_border_zero_kernel, dim3(d->B * (OH + 2 * z_pad)), dim3(256), 0, (hipStream_t)stream, (uint4*)z, OH, OW, cpp, z_pad);
-    FVA_LAUNCH_CHECK("halo_border_zero_kernel");
-    return FVA_OK;
+    return fva_zero_halo_border(z, d->B, OH, OW, d->Cout * (d->dtype == FVA_BF16 ? 2 : 4) / 16, z_pad, (hipStream_t)stream);
 }
 
 int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream) {

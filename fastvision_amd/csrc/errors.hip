@@ -54,3 +54,29 @@ extern "C" int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32
     g_used = 0;
     return n;
 }
+
+// ---- halo border ------------------------------------------------------------------------------------------------------
+namespace {
+// zero border of a halo NHWC buffer [B][H+2p][W+2p][C] (16-byte pieces): one block per padded row
+__global__ __launch_bounds__(256) void halo_border_zero_kernel(uint4* __restrict__ z, int H, int W, int cpp, int pad) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int yp = blockIdx.x % Hp;
+    uint4* row = z + (int64_t)blockIdx.x * Wp * cpp;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (yp < pad || yp >= H + pad) {
+        for (int i = threadIdx.x; i < Wp * cpp; i += 256) row[i] = zero;
+    } else {
+        for (int i = threadIdx.x; i < 2 * pad * cpp; i += 256) {
+            const int side = i / (pad * cpp), j = i - side * pad * cpp;
+            row[(side ? (W + pad) * cpp : 0) + j] = zero;
+        }
+    }
+}
+}  // namespace
+
+int fva_zero_halo_border(void* z, int B, int H, int W, int cpp, int pad, hipStream_t stream) {
+    if (pad <= 0) return FVA_OK;
+    hipLaunchKernelGGL(halo_border_zero_kernel, dim3(B * (H + 2 * pad)), dim3(256), 0, stream, (uint4*)z, H, W, cpp, pad);
+    FVA_LAUNCH_CHECK("halo_border_zero_kernel");
+    return FVA_OK;
+}

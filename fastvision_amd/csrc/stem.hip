@@ -208,15 +208,15 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const uint2* __restrict__ img4, const float* __restrict__ w,
-                                                            bf16_t* __restrict__ y, float* __restrict__ stats, int Cin, int H, int W,
-                                                            int64_t M) {
-    __shared__ float red[2][4][32];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int Wp = W + 2;
-    // weight fragments: A[co = 16c + r][k = 32s + 8g + j], k = kh*12 + kw*4 + ci
-    bf16x8 wa[2][2];
+// A-operand fragments of the 32 x 27 filter bank for the 16x16x32 MFMA: A[row][k = 32s + 8g + j], k = kh*12 + kw*4 + ci (K padded
+// 36 -> 64 with zeros).  The bank is staged through LDS by the whole block first: 64 dependent scalar loads per wave cost more
+// than the tile loop they precede.  CONTIG: MFMA row r of half c is channel 8(r/4) + 4c + r%4 (a lane's eight accumulators are
+// then eight contiguous channels) instead of 16c + r.
+template <bool CONTIG>
+__device__ inline void stem_weight_fragments(const float* __restrict__ w, int Cin, float* wsh, bf16x8 (&wa)[2][2]) {
+    const int tid = threadIdx.x, r = tid & 15, g = (tid & 63) >> 4;
+    for (int i = tid; i < CO * Cin * 9; i += 256) wsh[i] = w[i];
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -225,10 +225,23 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const uint2* __restr
             for (int j = 0; j < 8; ++j) {
                 const int k = 32 * s + 8 * g + j;
                 const int kh = k / 12, kw = (k % 12) / 4, ci = k & 3;
-                float v = 0.f;
-                if (k < 36 && ci < Cin) v = w[(((16 * c + r) * Cin + ci) * 3 + kh) * 3 + kw];
-                wa[c][s][j] = (bf16_t)v;
+                const int ch = CONTIG ? 8 * (r >> 2) + 4 * c + (r & 3) : 16 * c + r;
+                const bool live = k < 36 && ci < Cin;
+                const float v = wsh[live ? ((ch * Cin + ci) * 3 + kh) * 3 + kw : 0];
+                wa[c][s][j] = (bf16_t)(live ? v : 0.f);
             }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const uint2* __restrict__ img4, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ y, float* __restrict__ stats, int Cin, int H, int W,
+                                                            int64_t M) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int Wp = W + 2;
+    __shared__ float wsh[CO * 27];
+    bf16x8 wa[2][2];
+    stem_weight_fragments<false>(w, Cin, wsh, wa);
     // patch fragment: taps t = 2g, 2g + 1 (k-step 0) and t = 8 for g == 0 (k-step 1); tap t sits at (t / 3, t % 3)
     const int ta = 2 * g, tb = 2 * g + 1;
     const int offa = (ta / 3) * Wp + ta % 3, offb = (tb / 3) * Wp + tb % 3, offc = 2 * Wp + 2;
@@ -296,7 +309,171 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const uint2* __restr
     }
 }
 
+// ---- conv0 recomputed inside its own BatchNorm / SiLU passes (bf16 training) -----------------------------------------------
+// conv0 costs ~0.05 ms of MFMA time, its 32-channel 640x640 output 839 MB per trip through HBM.  So the pre-BN output is never
+// stored: each of the four passes that need it recomputes it from the 105 MB NHWC4 image copy, tile by tile, in registers.
+//   STATS   forward pass 1: per-block partial sums of y, y^2                        (then fva_bn_finalize)
+//   APPLY   forward pass 2: z = SiLU(y * scale + shift) into the halo buffer the next conv reads
+//   REDUCE  backward pass 1: partial sums of dU, dU * xhat (dU = dz * SiLU'(u))     (then fva_bn_bwd_finalize)
+//   DGRAD   backward pass 2: dY = a * dU + k1 * y + k2 into the halo buffer the weight gradient reads
+// HBM per pixel: 8 B (image) [+ 64 B dz] [+ 64 B z / dY] instead of an extra 64 B for y in every pass.
+enum { STEM_STATS = 0, STEM_APPLY = 1, STEM_REDUCE = 2, STEM_DGRAD = 3 };
+
+struct StemFusedParams {
+    const uint2* img4;
+    const float* w;
+    const bf16_t* dz;      // dense [M][32]                               (REDUCE, DGRAD)
+    const float *scale, *shift, *mean, *rstd, *coef;
+    bf16_t* out;           // halo [B][H+2][W+2][32], interior written    (APPLY, DGRAD)
+    float* part;           // [blocks][2][32]                             (STATS, REDUCE)
+    int Cin, H, W;
+    int64_t M;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void stem_fused_kernel(const StemFusedParams p) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W, Wp = W + 2;
+    __shared__ float wsh[CO * 27];
+    bf16x8 wa[2][2];
+    stem_weight_fragments<true>(p.w, p.Cin, wsh, wa);
+    const int ta = 2 * g, tb = 2 * g + 1;
+    const int offa = (ta / 3) * Wp + ta % 3, offb = (tb / 3) * Wp + tb % 3, offc = 2 * Wp + 2;
+    // this lane's eight accumulators are the contiguous channels 8g + 4c + j: one 16-byte access per pixel
+    float sc[2][4], sh[2][4], mu[2][4], rs[2][4], ka[2][4], k1[2][4], k2[2][4], s1[2][4], s2[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 8 * g + 4 * c + j;
+            s1[c][j] = s2[c][j] = 0.f;
+            if constexpr (MODE != STEM_STATS) {
+                sc[c][j] = p.scale[ch];
+                sh[c][j] = p.shift[ch];
+            }
+            if constexpr (MODE == STEM_REDUCE || MODE == STEM_DGRAD) {
+                mu[c][j] = p.mean[ch];
+                rs[c][j] = p.rstd[ch];
+            }
+            if constexpr (MODE == STEM_DGRAD) {
+                ka[c][j] = p.coef[ch];
+                k1[c][j] = p.coef[32 + ch] * rs[c][j];
+                k2[c][j] = p.coef[64 + ch] - k1[c][j] * mu[c][j];
+            }
+        }
+
+    // persistent waves: chunks of STEM_TPW consecutive tiles, strided over the grid.  A chunk's first tile is decoded once, the
+    // rest step along the row.  The pass is bound by load latency, not by bytes or MFMA time, so a wave issues the operands of
+    // STEM_NB tiles back to back before it computes any of them.
+    constexpr int STEM_NB = MODE == STEM_REDUCE ? 2 : 4;                         // REDUCE is VALU-bound as well: it keeps the registers for a fourth wave
+    const int tiles_per_row = W / 16;
+    const int nchunks = (int)((p.M / 16 + STEM_TPW - 1) / STEM_TPW);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);                         // wave-uniform: tile positions live in SGPRs
+    for (int chunk = blockIdx.x * 4 + wvu; chunk < nchunks; chunk += gridDim.x * 4) {
+    const int tile0 = chunk * STEM_TPW;
+    int64_t m0 = (int64_t)tile0 * 16;
+    const int row0 = tile0 / tiles_per_row;
+    int x0 = (tile0 - row0 * tiles_per_row) * 16;
+    const int b0 = row0 / H;
+    int yy = row0 - b0 * H;
+    int64_t hpix = ((int64_t)b0 * (H + 2) + yy) * Wp + x0;                      // halo pixel of tap (0, 0) of the tile's first pixel
+    for (int bt = 0; bt < STEM_TPW / STEM_NB; ++bt) {
+    uint2 la[STEM_NB], lb[STEM_NB], lc[STEM_NB];
+    bf16x8 gz[STEM_NB];
+    int64_t hp[STEM_NB];
+    bool ok[STEM_NB];
+#pragma unroll
+    for (int i = 0; i < STEM_NB; ++i) {
+        ok[i] = m0 < p.M;
+        hp[i] = hpix + r;
+        if (ok[i]) {
+            const uint2* base = p.img4 + hp[i];
+            la[i] = base[offa];
+            lb[i] = base[offb];
+            lc[i] = base[offc];
+            if constexpr (MODE == STEM_REDUCE || MODE == STEM_DGRAD) gz[i] = *(const bf16x8*)(p.dz + (m0 + r) * 32 + 8 * g);
+        }
+        m0 += 16;
+        x0 += 16;
+        hpix += 16;
+        if (x0 == W) {                                                          // next image row: skip the two halo columns
+            x0 = 0;
+            hpix += 2;
+            if (++yy == H) {                                                    // next image: skip its two halo rows
+                yy = 0;
+                hpix += 2 * Wp;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < STEM_NB; ++i) {
+        if (!ok[i]) break;
+        const bf16x8 p0 = __builtin_bit_cast(bf16x8, make_uint4(la[i].x, la[i].y, lb[i].x, lb[i].y));
+        const bf16x8 p1 = __builtin_bit_cast(bf16x8, g == 0 ? make_uint4(lc[i].x, lc[i].y, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u));
+        const bf16x8 gzc = gz[i];
+        const int64_t hcur = hp[i];
+        f32x4 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][0], p0, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][1], p1, acc[c], 0, 0, 0);
+        }
+        bf16_t* oo = nullptr;
+        if constexpr (MODE == STEM_APPLY || MODE == STEM_DGRAD) oo = p.out + (hcur + Wp + 1) * 32 + 8 * g;   // interior pixel (y, x)
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float yv = acc[c][j];
+                if constexpr (MODE == STEM_STATS) {
+                    s1[c][j] += yv;
+                    s2[c][j] += yv * yv;
+                } else if constexpr (MODE == STEM_APPLY) {
+                    o[4 * c + j] = (bf16_t)silu_f(yv * sc[c][j] + sh[c][j]);
+                } else {
+                    const float du = (float)gzc[4 * c + j] * silu_grad(yv * sc[c][j] + sh[c][j]);
+                    if constexpr (MODE == STEM_REDUCE) {
+                        s1[c][j] += du;
+                        s2[c][j] += du * (yv - mu[c][j]) * rs[c][j];
+                    } else {
+                        o[4 * c + j] = (bf16_t)(ka[c][j] * du + k1[c][j] * yv + k2[c][j]);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == STEM_APPLY || MODE == STEM_DGRAD) *(bf16x8*)oo = o;
+    }
+    }
+    }
+    if constexpr (MODE == STEM_STATS || MODE == STEM_REDUCE) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[c][j] += __shfl_xor(s1[c][j], o);
+                    s2[c][j] += __shfl_xor(s2[c][j], o);
+                }
+                if (r == 0) {
+                    red[0][wv][8 * g + 4 * c + j] = s1[c][j];
+                    red[1][wv][8 * g + 4 * c + j] = s2[c][j];
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5, ch = tid & 31;
+            p.part[((int64_t)blockIdx.x * 2 + which) * 32 + ch] = (red[which][0][ch] + red[which][1][ch]) + (red[which][2][ch] + red[which][3][ch]);
+        }
+    }
+}
+
 constexpr int WGRAD_BLOCKS = 1024;
+constexpr int STEM_FUSED_GRID = 2048;   // persistent blocks of the fused stem passes: 8 per CU
 
 }  // namespace
 
@@ -369,6 +546,53 @@ int fva_stem_wgrad(int dtype, const float* img, const void* dy, float* dw, int a
     const int n = Cout * Cin * 9;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(n), dim3(256), 0, s, (const float*)workspace, dw, n, grid, accumulate);
     FVA_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
+    return FVA_OK;
+}
+
+/* conv0 fused with its BatchNorm / SiLU passes (bf16, W % 16 == 0): see stem_fused_kernel.  mode 0 STATS -> part; 1 APPLY ->
+ * out (halo z, border zeroed here); 2 REDUCE -> part; 3 DGRAD -> out (halo dY, border zeroed here).  img4 = the NHWC4 image
+ * copy (fva_stem_pack); part has fva_stem_fused_blocks() rows of [2][32]; unused pointers may be NULL. */
+int32_t fva_stem_fused_blocks(int B, int H, int W) {
+    const int64_t blocks = cdiv((int64_t)B * H * W, STEM_BLOCK_PIX);
+    return (int32_t)(blocks < STEM_FUSED_GRID ? blocks : STEM_FUSED_GRID);
+}
+
+int fva_stem_pack(const float* img, void* img4, int64_t img4_bytes, int B, int Cin, int H, int W, void* stream) {
+    if (!img || !img4 || Cin < 1 || Cin > 3) return fva_fail(FVA_ERR_ARG, "fva_stem_pack: bad argument");
+    const int64_t need = fva_stem_fwd_workspace(FVA_BF16, B, H, W);
+    if (need == 0) return fva_fail(FVA_ERR_ARG, "fva_stem_pack: W = %d is not a multiple of 16", W);
+    if (img4_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_stem_pack: buffer %lld < %lld", (long long)img4_bytes, (long long)need);
+    const int64_t hp = (need - 64) / 8;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((int)((hp + 255) / 256 < 65536 ? (hp + 255) / 256 : 65536)), dim3(256), 0, (hipStream_t)stream, img,
+                       (uint2*)img4, B, Cin, H, W);
+    FVA_LAUNCH_CHECK("stem_pack_kernel");
+    return FVA_OK;
+}
+
+int fva_stem_fused(int mode, const void* img4, const float* w, const void* dz, const float* scale, const float* shift, const float* mean,
+                   const float* rstd, const float* coef, void* out, float* part, int B, int Cin, int H, int W, void* stream) {
+    if (!img4 || !w || Cin < 1 || Cin > 3 || W % 16) return fva_fail(FVA_ERR_ARG, "fva_stem_fused: bad argument");
+    const bool need_affine = mode != STEM_STATS, need_dz = mode == STEM_REDUCE || mode == STEM_DGRAD;
+    if ((need_affine && (!scale || !shift)) || (need_dz && (!dz || !mean || !rstd)) || (mode == STEM_DGRAD && !coef) ||
+        ((mode == STEM_APPLY || mode == STEM_DGRAD) && !out) || ((mode == STEM_STATS || mode == STEM_REDUCE) && !part))
+        return fva_fail(FVA_ERR_ARG, "fva_stem_fused: missing operand for mode %d", mode);
+    StemFusedParams p{};
+    p.img4 = (const uint2*)img4; p.w = w; p.dz = (const bf16_t*)dz;
+    p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.coef = coef;
+    p.out = (bf16_t*)out; p.part = part;
+    p.Cin = Cin; p.H = H; p.W = W; p.M = (int64_t)B * H * W;
+    if (p.M / 16 > INT32_MAX) return fva_fail(FVA_ERR_ARG, "fva_stem_fused: batch of %lld pixels too large", (long long)p.M);
+    const dim3 grid(fva_stem_fused_blocks(B, H, W));
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case STEM_STATS: hipLaunchKernelGGL(stem_fused_kernel<STEM_STATS>, grid, dim3(256), 0, s, p); break;
+        case STEM_APPLY: hipLaunchKernelGGL(stem_fused_kernel<STEM_APPLY>, grid, dim3(256), 0, s, p); break;
+        case STEM_REDUCE: hipLaunchKernelGGL(stem_fused_kernel<STEM_REDUCE>, grid, dim3(256), 0, s, p); break;
+        case STEM_DGRAD: hipLaunchKernelGGL(stem_fused_kernel<STEM_DGRAD>, grid, dim3(256), 0, s, p); break;
+        default: return fva_fail(FVA_ERR_ARG, "fva_stem_fused: bad mode %d", mode);
+    }
+    FVA_LAUNCH_CHECK("stem_fused_kernel");
+    if (mode == STEM_APPLY || mode == STEM_DGRAD) return fva_zero_halo_border(out, B, H, W, 4, 1, s);
     return FVA_OK;
 }
 

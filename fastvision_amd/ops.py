@@ -366,12 +366,31 @@ class StemFn(torch.autograd.Function):
         lib = _lib.load()
         dev, code = img.device, _code(dtype)
         M = B * H * W
-        y = torch.empty((M, Cout), dtype=dtype, device=dev)
         scale = torch.empty(Cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
         mean = rstd = None
         wsb = lib.fva_stem_fwd_workspace(code, B, H, W)           # bf16 NHWC4 copy of the images for the MFMA kernel
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        if ws is not None and os.environ.get('FVA_STEM_FUSED', '1') != '0':
+            # bf16: conv0's pre-BN output is never stored; the statistics pass and the apply pass each recompute it on MFMA
+            # from the packed image (839 MB of HBM traffic saved per pass at B = 32, 640 px)
+            _lib.call('fva_stem_pack', _p(img), _p(ws), wsb, B, Cin, H, W, _stream())
+            if training:
+                nblk = lib.fva_stem_fused_blocks(B, H, W)
+                stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
+                _lib.call('fva_stem_fused', 0, _p(ws), _p(weight), None, None, None, None, None, None, None, _p(stats), B, Cin, H, W, _stream())
+                mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
+                _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                          bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+            else:
+                _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
+            zbuf, z = halo_alloc(B, Cout, H, W, dtype, dev, 1)
+            _lib.call('fva_stem_fused', 1, _p(ws), _p(weight), None, _p(scale), _p(shift), None, None, None, _p(zbuf), None, B, Cin, H, W,
+                      _stream())
+            ctx.saved = (img, None, scale, shift, mean, rstd, gamma, dtype, training, tuple(weight.shape))
+            ctx.img4, ctx.weight = ws, weight.detach()
+            return z
+        y = torch.empty((M, Cout), dtype=dtype, device=dev)
         if training:
             nblk = lib.fva_stem_stat_blocks(code, B, H, W)
             stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
@@ -400,6 +419,25 @@ class StemFn(torch.autograd.Function):
         Cout, code, dev = wshape[0], _code(dtype), img.device
         M = B * H * W
         keep, dz_ptr = to_dense(dz, dtype)
+        if y is None:
+            # fused bf16 path: both BatchNorm-backward passes recompute conv0 from the packed image, dY lands in a halo buffer
+            w = ctx.weight
+            nb = lib.fva_stem_fused_blocks(B, H, W)
+            part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+            _lib.call('fva_stem_fused', 2, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), None, None,
+                      _p(part), B, Cin, H, W, _stream())
+            dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+            _lib.call('fva_bn_bwd_finalize', _p(part), nb, M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+            dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
+            _lib.call('fva_stem_fused', 3, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
+                      _p(dy), None, B, Cin, H, W, _stream())
+            raw = torch.empty((Cout, 4, 4, 3), dtype=torch.float32, device=dev)        # [co][kw][ci][kh]
+            wsb = lib.fva_stem_wgrad_mfma_workspace()
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.call('fva_stem_wgrad_mfma', _p(ctx.img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
+            return None, raw[:, :3, :Cin, :].permute(0, 2, 3, 1).contiguous(), dgamma, dbeta, None, None, None
         nb = lib.fva_bn_bwd_blocks(code, M, Cout)
         part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(part),

@@ -122,6 +122,7 @@ int fva_stem_fwd(int dtype, const float* images_nchw, const float* w_oihw, void*
                  void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
 int64_t fva_stem_fwd_workspace(int dtype, int B, int H, int W);
 int32_t fva_stem_stat_blocks(int dtype, int B, int H, int W);
+int32_t fva_stem_fused_blocks(int B, int H, int W);   /* partial rows written by fva_stem_fused modes 0 and 2 */
 int fva_stem_wgrad(int dtype, const float* images_nchw, const void* dy, float* dw_oihw, int accumulate,
                    void* workspace, int64_t workspace_bytes, int B, int Cin, int H, int W, int Cout, void* stream);
 int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
@@ -130,6 +131,14 @@ int64_t fva_stem_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
 int fva_stem_wgrad_mfma(const void* images_nhwc4, const void* dy_halo, float* dw_raw, void* workspace, int64_t workspace_bytes,
                         int B, int H, int W, void* stream);
 int64_t fva_stem_wgrad_mfma_workspace(void);
+/* bf16 training form that never stores conv0's pre-BN output: the four BatchNorm / SiLU passes recompute it on MFMA from the
+ * NHWC4 image copy (fva_stem_pack; fva_stem_fwd_workspace() bytes).  mode 0: partial sums of y, y^2 -> part; 1: z = SiLU(BN(y))
+ * -> halo buffer out [B][H+2][W+2][32]; 2: partial sums of dU, dU*xhat from dz (dense [B*H*W][32]) -> part; 3: dY -> halo
+ * buffer out.  part: fva_stem_fused_blocks() rows of [2][32], reduced by fva_bn_finalize / fva_bn_bwd_finalize. */
+int fva_stem_pack(const float* images_nchw, void* images_nhwc4, int64_t bytes, int B, int Cin, int H, int W, void* stream);
+int fva_stem_fused(int mode, const void* images_nhwc4, const float* w_oihw, const void* dz, const float* scale, const float* shift,
+                   const float* save_mean, const float* save_rstd, const float* coef, void* out, float* part, int B, int Cin, int H,
+                   int W, void* stream);
 
 /* Head: biased 1x1 conv to N = A*(5+C) channels (detection/head/yolov3head.py:50,60;
  * demos/yolov3_u/models/yolov3.py:119-135).  Output fp32, dense [B*H*W][N] (pixel-major, N contiguous):

@@ -387,3 +387,28 @@ def test_stem_wgrad_mfma_matches_direct_kernel():
     got = raw[:, :3, :3, :].permute(0, 2, 3, 1)
     want = torch.nn.grad.conv2d_weight(img.bfloat16().float(), w.shape, gy.float().permute(0, 3, 1, 2), padding=1)
     assert rel_err(got, want) < 1e-4, rel_err(got, want)
+
+
+def test_stem_fused_passes_equal_unfused_path(monkeypatch):
+    """bf16 stem block (conv0 + BN + SiLU, forward and backward) with conv0 recomputed inside the four BatchNorm passes
+    against the path that stores the pre-BN output: same z, dW, dgamma, dbeta and running statistics up to the bf16
+    rounding of the stored intermediate (the fused path keeps it in fp32 registers)."""
+    import fastvision_amd
+    from fastvision_amd.classfication.models.darknet53 import ConvBlock3x3
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(4, 3, 32, 48, generator=g).to(dev())
+    gz = torch.randn(4, 32, 32, 48, generator=g).to(dev())
+    res = {}
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        for flag in ('1', '0'):
+            monkeypatch.setenv('FVA_STEM_FUSED', flag)
+            torch.manual_seed(4)
+            blk = ConvBlock3x3(3, 32, stride=(1, 1)).to(dev()).train()
+            z = blk(img)
+            z.backward(gz.to(z.dtype))
+            res[flag] = (z.detach().float(), blk.conv.weight.grad.clone(), blk.bn.weight.grad.clone(), blk.bn.bias.grad.clone(),
+                         blk.bn.running_mean.clone(), blk.bn.running_var.clone())
+    names = ('z', 'dW', 'dgamma', 'dbeta', 'running_mean', 'running_var')
+    for name, a, b in zip(names, res['1'], res['0']):
+        assert rel_err(a, b) < 2e-2, (name, rel_err(a, b))
+    assert rel_err(res['1'][4], res['0'][4]) < 1e-4 and rel_err(res['1'][5], res['0'][5]) < 1e-4
