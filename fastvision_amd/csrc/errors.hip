@@ -10,10 +10,11 @@ struct Span { hipEvent_t e0, e1; int cls; double flop; };
 std::vector<Span> g_spans;     // events are created by fva_profile_start, i.e. outside whatever the caller is timing
 int g_used = 0;
 bool g_on = false;
+unsigned g_mask = ~0u;         // classes that are bracketed while armed (bit = class)
 }  // namespace
 
 FvaProfileSpan::FvaProfileSpan(int cls, double flop, hipStream_t s) : slot(-1), stream(s) {
-    if (!g_on || g_used >= (int)g_spans.size()) return;
+    if (!g_on || !((g_mask >> cls) & 1u) || g_used >= (int)g_spans.size()) return;
     slot = g_used++;
     g_spans[slot].cls = cls;
     g_spans[slot].flop = flop;
@@ -36,6 +37,11 @@ extern "C" int fva_profile_start(int32_t max_spans) {
     (void)hipDeviceSynchronize();
     g_used = 0;
     g_on = true;
+    return FVA_OK;
+}
+
+extern "C" int fva_profile_classes(uint32_t mask) {
+    g_mask = mask;
     return FVA_OK;
 }
 

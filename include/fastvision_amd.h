@@ -45,8 +45,12 @@ int fva_version(void);
 /* Live timing of the MFMA convolution entry points with HIP events on their launch stream, taken inside the library (no
  * per-call host work in the caller).  fva_profile_start(max_spans) creates the events -- call it OUTSIDE the region being
  * timed -- and arms the spans; fva_profile_stop() synchronises the device, disarms and returns the number of spans with
- * cls (0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce), algorithmic FLOPs and elapsed milliseconds of each. */
+ * cls (0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce), algorithmic FLOPs and elapsed milliseconds of each.
+ * fva_profile_classes(mask) restricts the spans to the classes whose bit is set (default: all): every span costs two event
+ * packets on the stream, ~2 us of GPU idle time each, which a throughput measurement should only pay for the kernel class
+ * it reports. */
 int fva_profile_start(int32_t max_spans);
+int fva_profile_classes(uint32_t mask);
 int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------
