@@ -11,10 +11,11 @@ std::vector<Span> g_spans;     // events are created by fva_profile_start, i.e. 
 int g_used = 0;
 bool g_on = false;
 unsigned g_mask = ~0u;         // classes that are bracketed while armed (bit = class)
+int g_stride = 1, g_seen = 0;  // of the eligible calls every g_stride-th is bracketed
 }  // namespace
 
 FvaProfileSpan::FvaProfileSpan(int cls, double flop, hipStream_t s) : slot(-1), stream(s) {
-    if (!g_on || !((g_mask >> cls) & 1u) || g_used >= (int)g_spans.size()) return;
+    if (!g_on || !((g_mask >> cls) & 1u) || (g_seen++ % g_stride) != 0 || g_used >= (int)g_spans.size()) return;
     slot = g_used++;
     g_spans[slot].cls = cls;
     g_spans[slot].flop = flop;
@@ -40,8 +41,11 @@ extern "C" int fva_profile_start(int32_t max_spans) {
     return FVA_OK;
 }
 
-extern "C" int fva_profile_classes(uint32_t mask) {
+extern "C" int fva_profile_classes(uint32_t mask, int32_t stride) {
+    if (stride < 1) return fva_fail(FVA_ERR_ARG, "fva_profile_classes: stride must be >= 1");
     g_mask = mask;
+    g_stride = stride;
+    g_seen = 0;
     return FVA_OK;
 }
 
@@ -59,6 +63,43 @@ extern "C" int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32
     }
     g_used = 0;
     return n;
+}
+
+// ---- side stream ------------------------------------------------------------------------------------------------------
+// The weight gradient of a layer has no consumer before the optimizer, so it can run beside the rest of the backward pass:
+// a low-priority stream whose blocks fill the CUs that the partly empty last round of a dgrad launch (256x256 tiles: 800,
+// 400 or 200 tiles on 256 CUs) and the HBM-bound BatchNorm passes leave idle.  fork: the side stream waits for everything
+// enqueued on `main` so far; join: `main` waits for everything enqueued on the side stream so far.
+namespace {
+hipStream_t g_side = nullptr;
+hipEvent_t g_side_ev[64];
+int g_side_next = 0;
+hipEvent_t side_event() { return g_side_ev[g_side_next++ & 63]; }
+}  // namespace
+
+extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
+    if (!side_stream) return fva_fail(FVA_ERR_ARG, "fva_side_stream_fork: null pointer");
+    if (!g_side) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess)
+            return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_fork: cannot create the side stream");
+        for (auto& e : g_side_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_fork: hipEventCreate failed");
+    }
+    hipEvent_t e = side_event();
+    if (hipEventRecord(e, (hipStream_t)main_stream) != hipSuccess || hipStreamWaitEvent(g_side, e, 0) != hipSuccess)
+        return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_fork: event record / wait failed");
+    *side_stream = (void*)g_side;
+    return FVA_OK;
+}
+
+extern "C" int fva_side_stream_join(void* main_stream) {
+    if (!g_side) return FVA_OK;
+    hipEvent_t e = side_event();
+    if (hipEventRecord(e, g_side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main_stream, e, 0) != hipSuccess)
+        return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_join: event record / wait failed");
+    return FVA_OK;
 }
 
 // ---- halo border ------------------------------------------------------------------------------------------------------

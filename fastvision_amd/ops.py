@@ -291,6 +291,72 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     return z, s
 
 
+# ---- weight gradients beside the rest of the backward pass ----------------------------------------------------------------
+# Nothing reads a layer's dW before the optimizer (or the gradient all-reduce), so the wgrad launches go to the library's
+# low-priority side stream: their blocks fill the CUs that the partly empty last round of the dgrad launches (800 / 400 / 200
+# tiles of 256x256 on 256 CUs) and the HBM-bound BatchNorm passes leave idle.  The fork/join events are recorded inside the
+# library (two HIP calls per layer); the buffers the side stream touches are simply kept referenced until the join, which a
+# callback queued on the autograd engine performs at the end of the backward pass (anything that reads .grad earlier -- the
+# gradient-bucket hooks of parallel.GradientReducer -- joins first through join_side_stream()).
+_SIDE = {'on': os.environ.get('FVA_WGRAD_STREAM', '1') != '0', 'keep': [], 'queued': False, 'torch': None}
+
+
+def join_side_stream(force=False):
+    """Make the current stream wait for everything launched on the side stream so far; release the buffers held for it."""
+    if force or _SIDE['keep'] or _SIDE['queued']:
+        _lib.call('fva_side_stream_join', _stream())
+        _SIDE['keep'].clear()
+        _SIDE['queued'] = False
+
+
+def fork_side_stream():
+    """torch handle of the side stream, after making it wait for the current stream -- or None when the side stream is off.
+    For consumers of a gradient that is still in flight there (the bucket copies / all-reduces of parallel.GradientReducer):
+    work they enqueue on the handle runs after the weight gradients launched so far, without stalling the backward pass."""
+    if not _SIDE['on']:
+        return None
+    side = C.c_void_p()
+    _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
+    if _SIDE['torch'] is None or _SIDE['torch'].cuda_stream != side.value:
+        _SIDE['torch'] = torch.cuda.ExternalStream(side.value)
+    return _SIDE['torch']
+
+
+def set_wgrad_side_stream(on):
+    """Switch the side stream for weight gradients on or off (default on; env FVA_WGRAD_STREAM=0 turns it off).  Returns the
+    previous setting.  Off = every kernel of the step runs on the caller's stream, one after the other (exclusive timings)."""
+    prev = _SIDE['on']
+    if prev and not on:
+        join_side_stream(force=True)
+    _SIDE['on'] = bool(on)
+    return prev
+
+
+def hold_for_side_stream(*buffers):
+    """Keep tensors that work on the side stream still reads or writes referenced until the next join (their memory would
+    otherwise return to the allocator, which hands it to the next main-stream allocation)."""
+    if _SIDE['on']:
+        _SIDE['keep'].append(buffers)
+
+
+def wgrad_stream(buffers, weight=None):
+    """Stream argument for a weight-gradient launch (called from inside a backward pass).  A parameter that already holds a
+    gradient (accumulation over micro-batches) gets its dW added by autograd on the main stream right after this backward
+    returns, so that layer stays on the main stream; so does everything under create_graph."""
+    if not _SIDE['on'] or torch.is_grad_enabled() or (weight is not None and weight.grad is not None):
+        return _stream()
+    side = C.c_void_p()
+    _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
+    _SIDE['keep'].append(buffers)
+    if not _SIDE['queued']:
+        _SIDE['queued'] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        except RuntimeError:                      # not inside an engine-driven backward pass: the caller joins
+            pass
+    return side
+
+
 def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     """Backward of conv_block_fwd given dz (dense NHWC, dtype).  Returns (dx_buf or None, dw, dgamma, dbeta)."""
     if not s.training:
@@ -311,11 +377,8 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
               _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
-    # wgrad runs on the launch stream, ahead of dgrad.  (Launching it on a low-priority side stream and joining once at the
-    # end of backward measured +1-2 %, at the price of 8 ms of host time per step and overlapped per-kernel timings: not
-    # worth the machinery -- DESIGN.md section 5.)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, _stream())
+    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, wgrad_stream((s.x, getattr(s, 'keep', None), dy, ws), s.weight))     # NOT dw: a second reference makes AccumulateGrad clone it (on the main stream)
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)

@@ -55,6 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .ops import join_side_stream
+        join_side_stream()          # weight gradients may still be in flight on the library's side stream
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue

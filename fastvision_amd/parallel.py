@@ -12,6 +12,8 @@ xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound by one l
 backbone), i.e. in the order backward produces gradients, so the first buckets fly while the backbone is still in
 backward.  ``torch.distributed`` is the transport (backend "nccl" is RCCL on ROCm; "gloo" for CPU tests).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -101,14 +103,29 @@ class GradientReducer:
         self.handles = [None] * len(self.buckets)
         self.next_launch = 0
 
+    def _side(self, p):
+        """Context in which a gradient of ``p`` may be read: weight gradients are computed on the library's low-priority
+        side stream (ops.wgrad_stream), so the bucket copies and the all-reduce launches are enqueued there too, behind
+        them -- the backward pass on the main stream is not stalled.  finish() joins."""
+        if p.is_cuda:
+            from .ops import fork_side_stream
+            st = fork_side_stream()
+            if st is not None:
+                return torch.cuda.stream(st)
+        return contextlib.nullcontext()
+
     def _on_grad(self, p):
         bi, vi = self.where[p]
         view = self.buckets[bi][2][vi]
-        if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
-            p.grad = view                                  # the optimizer reads the (soon averaged) bucket
-        self.pending[bi] -= 1
-        self._launch_ready()
+        with self._side(p):
+            if p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                if p.is_cuda:
+                    from .ops import hold_for_side_stream
+                    hold_for_side_stream(p.grad)           # still being written / read on the side stream
+                p.grad = view                              # the optimizer reads the (soon averaged) bucket
+            self.pending[bi] -= 1
+            self._launch_ready()
 
     def _launch_ready(self):
         while self.next_launch < len(self.buckets) and self.pending[self.next_launch] <= 0:
@@ -128,6 +145,9 @@ class GradientReducer:
     def finish(self):
         """Launch what is still outstanding (parameters that received no gradient contribute zeros), wait for every
         collective and re-arm for the next step."""
+        if self.params and self.params[0].is_cuda:
+            from .ops import join_side_stream
+            join_side_stream(force=True)
         for bi in range(self.next_launch, len(self.buckets)):
             flat, plist, views = self.buckets[bi]
             for p, v in zip(plist, views):

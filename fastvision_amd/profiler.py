@@ -134,15 +134,16 @@ class KernelTimer:
     while armed (more are simply not timed); the events are created in __enter__, before anything the caller times."""
     CLASSES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad')
 
-    def __init__(self, pool=4096, classes=None):
-        """classes: bracket only these (default all three).  A span costs two event packets on the stream (~2 us of GPU idle
-        time each), so a throughput run brackets just the class it reports."""
+    def __init__(self, pool=4096, classes=None, stride=1):
+        """classes: bracket only these (default all three); stride: of their calls, only every stride-th one.  A span costs
+        two event packets on the stream and ~7 us of GPU time, so a throughput run brackets a sample of the class it reports."""
         self.pool = int(pool)
         self.spans = None
         self.mask = sum(1 << self.CLASSES.index(c) for c in (classes or self.CLASSES))
+        self.stride = int(stride)
 
     def __enter__(self):
-        _lib.call('fva_profile_classes', self.mask)
+        _lib.call('fva_profile_classes', self.mask, self.stride)
         _lib.call('fva_profile_start', self.pool)
         return self
 
@@ -155,7 +156,7 @@ class KernelTimer:
             n = self.pool
             cls, flop, ms = (C.c_int32 * n)(), (C.c_double * n)(), (C.c_float * n)()
             got = _lib.load().fva_profile_stop(cls, flop, ms, n)
-            _lib.call('fva_profile_classes', 0xffffffff)
+            _lib.call('fva_profile_classes', 0xffffffff, 1)
             self.spans = [(self.CLASSES[cls[i]], flop[i], ms[i]) for i in range(got)]
         return self.spans
 

@@ -46,11 +46,19 @@ int fva_version(void);
  * per-call host work in the caller).  fva_profile_start(max_spans) creates the events -- call it OUTSIDE the region being
  * timed -- and arms the spans; fva_profile_stop() synchronises the device, disarms and returns the number of spans with
  * cls (0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce), algorithmic FLOPs and elapsed milliseconds of each.
- * fva_profile_classes(mask) restricts the spans to the classes whose bit is set (default: all): every span costs two event
- * packets on the stream, ~2 us of GPU idle time each, which a throughput measurement should only pay for the kernel class
- * it reports. */
+ * fva_profile_classes(mask, stride) restricts the spans to the classes whose bit is set and, of those calls, to every
+ * stride-th one (default: all classes, stride 1).  A span costs two event packets on the stream and the kernels on either
+ * side of them no longer overlap their launch with the neighbour's tail (measured: ~7 us of GPU time per span, 3 % of the
+ * train step when every forward convolution is bracketed), so a throughput measurement brackets a sample of the kernel
+ * class it reports. */
 int fva_profile_start(int32_t max_spans);
-int fva_profile_classes(uint32_t mask);
+int fva_profile_classes(uint32_t mask, int32_t stride);
+
+/* A low-priority side stream for work that nothing waits for until the end of the backward pass (the weight gradients).
+ * fork: the side stream (returned) waits for everything enqueued on main_stream so far.  join: main_stream waits for
+ * everything enqueued on the side stream so far.  Buffers the side stream reads or writes must stay alive until a join. */
+int fva_side_stream_fork(void* main_stream, void** side_stream);
+int fva_side_stream_join(void* main_stream);
 int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------

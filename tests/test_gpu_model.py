@@ -377,6 +377,57 @@ def test_data_parallel_two_ranks_one_gpu():
         assert err < 1e-4, f'{k}: {err}'
 
 
+def _rccl_worker(rank, world, port, out):
+    import os
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import fastvision_amd
+    from fastvision_amd import FusedAdam, parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    images, tg = synthetic_batch(4, 128)
+    images, tg = images.to(DEV), tg.to(DEV)
+    res = {}
+    for mode in ('plain', 'reduced'):
+        net, crit = lib_model(), lib_loss()                                  # bf16 compute: the bench's kernels
+        opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+        red = None
+        if mode == 'reduced':
+            red = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20)
+            red.world = 2            # a one-rank group averages to the identity: forces the collectives to be ISSUED
+        for _ in range(2):
+            opt.zero_grad()
+            loss = crit(net(images), tg)
+            loss.backward()
+            if red is not None:
+                launched = red.next_launch
+                red.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        res[mode] = {k: p.detach().cpu().clone() for k, p in list(net.named_parameters())[::17]}
+        res[mode + '_grad'] = {k: p.grad.detach().cpu().clone() for k, p in list(net.named_parameters())[::17]}
+    out['res'] = (res, launched, len(red.buckets))
+    dist.destroy_process_group()
+
+
+def test_reducer_over_rccl_with_side_stream_single_rank():
+    """The N > 1 mechanics on the real backend (RCCL), as far as one GPU allows: a one-rank nccl group with the reducer
+    forced to issue its bucketed AVG all-reduces.  Weight gradients are computed on the library's low-priority side
+    stream; the bucket copies and collectives are enqueued behind them.  Two optimizer steps must give bit-identical
+    parameters and gradients to the same two steps without the reducer."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.start_processes(_rccl_worker, args=(1, port, out), nprocs=1, join=True, start_method='spawn')
+    res, launched, nb = out['res']
+    assert nb >= 8 and launched >= nb - 2                                   # collectives went out during backward
+    for k in res['plain']:
+        assert torch.equal(res['plain'][k], res['reduced'][k]), k
+        assert torch.equal(res['plain_grad'][k], res['reduced_grad'][k]), k
+
+
 def test_config2_fp32_full_size_vs_oracle():
     """BASELINE config 2 at full size: YOLOv3 8x3x416x416 fp32 (grids 13/26/52), one train step vs the CPU oracle on
     the same seeded batch: heads and loss within 1e-3, per-tensor gradient norms within 2e-3, matcher indices exact."""
