@@ -173,6 +173,23 @@ def main():
         for _ in range(probe_steps):
             step()
         fence()
+    # the shader clock under load: MI355X runs its matrix pipes well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at.
+    # One more untimed step with the 8-phase kernel's diagnostic stamps on: cycle counter / wall clock over each block's
+    # k-loop (bf16 only -- the 8-phase kernel is a bf16 kernel).
+    clock_mhz = None
+    if args.dtype == 'bf16':
+        import ctypes as C
+        from fastvision_amd import _lib as fva_lib
+        stamps = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
+        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(stamps.data_ptr()))
+        step()
+        fence()
+        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(0))
+        st = stamps.view(-1, 8).cpu()
+        st = st[st[:, 3] > 0]
+        if len(st):
+            wall_us = (st[:, 2] - st[:, 1]).double() / 100.0
+            clock_mhz = float(((st[:, 6] - st[:, 5]).double() / wall_us).median())
     fva_ops.set_wgrad_side_stream(side_was)
     step()
     fence()
@@ -222,7 +239,12 @@ def main():
                          'launches_per_step': probe_summ[dom]['launches'] // probe_steps, 'launches_timed': d['launches'],
                          'sampling': 'every launch' if args.shapes else f'every {SAMPLE_STRIDE}th launch of the class over the timed region',
                          'avg_launch_ms': round(d['ms_avg'], 4), 'gflop_per_launch': round(d['flop_per_launch'] / 1e9, 3),
-                         'ms_per_step': round(probe_summ[dom]['ms_total'] / probe_steps, 3)},
+                         'ms_per_step': round(probe_summ[dom]['ms_total'] / probe_steps, 3),
+                         'shader_clock_mhz_under_load': None if clock_mhz is None else round(clock_mhz),
+                         'peak_at_that_clock': None if clock_mhz is None else round(peak * clock_mhz / 2400.0, 1),
+                         'frac_at_that_clock': None if clock_mhz is None else round(d['tflops'] / (peak * clock_mhz / 2400.0), 4),
+                         'clock_note': 'peak is the nominal dense figure at 2400 MHz; the clock is the median, over the blocks of the 8-phase '
+                                       'convolution launches of one untimed step, of cycle counter / wall clock across the k-loop'},
             'kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / probe_steps, 3),
                             'launches_per_step': v['launches'] // probe_steps} for k, v in probe_summ.items()},
             'kernels_note': f'exclusive per-class figures: all classes bracketed on {probe_steps} untimed steps just before the '

@@ -424,6 +424,7 @@ struct StreamK {
     int32_t* flags;      // [grid] launch epoch of the slab + [grid] poll time-outs (diagnostic)
     int32_t epoch;
     int32_t tiles;
+    long long* stamps;   // diagnostic (fva_conv_debug_stamps): [grid][8], see the kernel's stamp()
 };
 
 template <int EPI, bool SK>
@@ -434,6 +435,13 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
+    auto stamp = [&](int i) {   // per block: 4 wall-clock stamps, then the shader-clock cycle counter at the same points (ratio = the clock under load)
+        if (sk.stamps && tid == 0) {
+            sk.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
+            sk.stamps[(int64_t)blockIdx.x * 8 + 4 + i] = clock64();
+        }
+    };
+    stamp(0);
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
@@ -572,6 +580,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+        stamp(1);
         if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
         for (int t = kt0; t < kt1; ++t) {
@@ -611,6 +620,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
         __syncthreads();                             // LDS is free for the epilogue
+        stamp(2);
         // everything below derives its addresses from this copy: computed after the loop, not carried (spilled) through it
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
@@ -745,6 +755,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             }
         }
     }
+    stamp(3);
 }
 
 constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16) + 4096;   // the epilogue's transposed tile (> 2 staging buffers) + k table
@@ -799,6 +810,8 @@ inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in
     return ktiles >= 24 || tiles <= 256;
 }
 
+long long* g_stamps = nullptr;   // fva_conv_debug_stamps
+
 template <int EPI>
 int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     IgemmParams q = p;
@@ -811,6 +824,7 @@ int launch_igemm8(const IgemmParams& p, hipStream_t s) {
         attr_done = true;
     }
     StreamK sk{};
+    sk.stamps = g_stamps;
     if (use_streamk(tiles, p.ktiles)) {
         sk.slabs = g_sk.slabs;
         sk.flags = g_sk.flags;
@@ -1022,6 +1036,11 @@ int fva_conv_set_workspace(void* ws, int64_t bytes) {
     g_sk.flags = (int32_t*)((char*)ws + (int64_t)cus * SK_SLAB_BYTES);
     g_sk.grid = cus;
     g_sk.epoch = 0;
+    return FVA_OK;
+}
+
+int fva_conv_debug_stamps(void* stamps) {
+    g_stamps = (long long*)stamps;
     return FVA_OK;
 }
 

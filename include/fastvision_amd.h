@@ -102,6 +102,10 @@ int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t 
 int64_t fva_conv_workspace_bytes(void);
 int fva_conv_set_workspace(void* workspace, int64_t bytes);
 int64_t fva_conv_streamk_timeouts(void);
+/* Diagnostic: while set (non-NULL), every block of an 8-phase convolution launch writes eight values to stamps[block * 8 ..]:
+ * wall_clock64 (100 MHz) at block entry, first k-tile ready, k-loop done and exit, then the shader-clock cycle counter at the
+ * same four points (cycles / wall time = the shader clock under load).  The buffer must hold the largest grid. */
+int fva_conv_debug_stamps(void* stamps);
 
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Where does a block of the 8-phase convolution kernel spend its time?  Per-block wall_clock64 stamps (100 MHz) written by
+the kernel itself (fva_conv_debug_stamps): entry -> first k-tile ready (prologue) -> k-loop done -> exit (epilogue).
+usage: python tools/tile_timing.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from fastvision_amd import _lib, ops
+
+SHAPES = [(32, 256, 512, 40, 3), (32, 512, 1024, 20, 3), (32, 512, 256, 40, 3)]      # (B, Cin, Cout, H, k); the last one is the 256->512 dgrad's shape run as a forward
+
+
+def main():
+    lib = _lib.load()
+    dev, dtype = 'cuda:0', torch.bfloat16
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+    for (B, Cin, Cout, H, k) in SHAPES:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev).to(dtype)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+        d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, k, 1, 1, 1)
+        wf, wd = ops.packed_weights(w, d, dtype, cache=False)
+        M = B * H * H
+        y = torch.empty(M, Cout, device=dev, dtype=dtype)
+        nblk = lib.fva_conv_stat_blocks(C.byref(d))
+        stats = torch.zeros(lib.fva_bn_partial_rows(nblk), 2, Cout, device=dev)
+        st = ops._stream()
+        for with_stats in (True, False):
+            sp = ops._p(stats) if with_stats else C.c_void_p(0)
+            fwd = lambda: _lib.call('fva_conv_fwd', C.byref(d), ops._p(x), ops._p(wf), ops._p(y), sp, st)
+            for _ in range(3):
+                fwd()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fwd()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            stamps.zero_()
+            _lib.call('fva_conv_debug_stamps', ops._p(stamps))
+            fwd()
+            torch.cuda.synchronize()
+            _lib.call('fva_conv_debug_stamps', C.c_void_p(0))
+            raw = stamps.cpu().numpy().reshape(-1, 8)
+            raw = raw[raw[:, 3] > 0]
+            s, cyc = raw[:, :4], raw[:, 4:]
+            mhz = np.median((cyc[:, 2] - cyc[:, 1]) / ((s[:, 2] - s[:, 1]) / 100.0))
+            t0 = s[:, 0].min()
+            rel = (s - t0) / 100.0                                   # microseconds since the first block started
+            pro, loop, epi = rel[:, 1] - rel[:, 0], rel[:, 2] - rel[:, 1], rel[:, 3] - rel[:, 2]
+            first = rel[:, 0] < 5.0                                  # blocks of the first round
+            tiles, kt = len(s), k * k * Cin // 64
+            print(f'{Cin}->{Cout} @{H} k{k} stats={int(with_stats)}: {tiles} tiles x {kt} k-tiles, launch {us:.1f} us, shader clock in the k-loop {mhz:.0f} MHz | '
+                  f'last exit {rel[:, 3].max():.1f} us | prologue {np.median(pro):.2f} loop {np.median(loop):.2f} '
+                  f'({np.median(loop) / kt * 1e3:.0f} ns/k-tile) epilogue {np.median(epi):.2f} us (medians) | '
+                  f'first-round blocks: {first.sum()}, start spread {rel[first, 0].max():.2f} us; '
+                  f'second-round starts {np.sort(rel[~first, 0])[:3].round(1).tolist() if (~first).any() else "-"}')
+
+
+if __name__ == '__main__':
+    main()
