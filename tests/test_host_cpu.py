@@ -205,3 +205,50 @@ def test_fit_run_epoches_contract(tmp_path, monkeypatch):
     ckpt = torch.load(tmp_path / 'last.pth', weights_only=False)
     assert set(ckpt) == {'model', 'optimizer', 'date'} and 'w' in ckpt['model']
     assert torch.allclose(ckpt['model']['w'], net.w.detach())
+
+
+def test_config1_resnet18_cpu_fit_plumbing(tmp_path, monkeypatch):
+    """BASELINE config 1: ResNet-18 classification, 32x3x224x224 synthetic, through utils/fit.py on the CPU -- plumbing only
+    (stock torch ops: the classification families are out of scope, the Fit loop is the caller of the accelerated path).
+    The reference drives `Fit._train` with a list-of-tuples loader, CrossEntropyLoss and SGD the same way."""
+    import torch
+    import torch.nn as nn
+    from fastvision_amd.utils import Fit
+    from fastvision_amd.utils.sheduler import LinearLR
+    monkeypatch.chdir(tmp_path)
+
+    class Block(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.c1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.b1 = nn.BatchNorm2d(cout)
+            self.c2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.b2 = nn.BatchNorm2d(cout)
+            self.down = None
+            if stride != 1 or cin != cout:
+                self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+        def forward(self, x):
+            y = self.b2(self.c2(torch.relu(self.b1(self.c1(x)))))
+            return torch.relu(y + (x if self.down is None else self.down(x)))
+
+    def resnet18(classes):
+        layers, cin = [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1)], 64
+        for cout, stride in ((64, 1), (128, 2), (256, 2), (512, 2)):
+            layers += [Block(cin, cout, stride), Block(cout, cout, 1)]
+            cin = cout
+        return nn.Sequential(*layers, nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(512, classes))
+
+    torch.manual_seed(0)
+    net = resnet18(10)
+    assert sum(p.numel() for p in net.parameters()) == 11_181_642            # ResNet-18 with a 10-way head
+    g = torch.Generator().manual_seed(1)
+    batch = (torch.rand(32, 3, 224, 224, generator=g), torch.randint(0, 10, (32,), generator=g))
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    sched = LinearLR(opt, steps=2, initial_lr=0.05, last_lr=0.005)
+    fit = Fit(net, torch.device('cpu'), opt, sched, nn.CrossEntropyLoss(), end_epoch=2, train_loader=[batch, batch])
+    fit.run_epoches()
+    losses = [l for epoch in fit.history for l in epoch]
+    assert len(losses) == 4 and all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]                                             # the same batch four times: it must fit it
+    assert (tmp_path / 'last.pth').exists()
