@@ -348,12 +348,13 @@ def wgrad_stream(buffers, weight=None):
     side = C.c_void_p()
     _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
     _SIDE['keep'].append(buffers)
-    if not _SIDE['queued']:
-        _SIDE['queued'] = True
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-        except RuntimeError:                      # not inside an engine-driven backward pass: the caller joins
-            pass
+    # one callback per launch, not one per backward pass: a pass that dies with an exception never runs its callbacks, and a
+    # "queued" flag left behind by it would leave the next pass without a join (all but the first callback find nothing to do)
+    _SIDE['queued'] = True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+    except RuntimeError:                          # not inside an engine-driven backward pass: the caller joins
+        pass
     return side
 
 

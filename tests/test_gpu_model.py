@@ -377,6 +377,38 @@ def test_data_parallel_two_ranks_one_gpu():
         assert err < 1e-4, f'{k}: {err}'
 
 
+def test_side_stream_gradient_consumers():
+    """Weight gradients run on the library's side stream (ops.wgrad_stream).  Three ways of consuming them must see finished
+    values: .grad after backward(), accumulation into an existing .grad (autograd adds on the main stream: those layers must
+    stay there), and torch.autograd.grad()."""
+    import fastvision_amd
+    from fastvision_amd import ops
+    assert ops._SIDE['on'], 'the side stream is the product default'
+    images, tg = synthetic_batch(2, 128)
+    images, tg = images.to(DEV), tg.to(DEV)
+    with fastvision_amd.compute_dtype(torch.float32):
+        net, crit = lib_model(), lib_loss()
+        params = [p for p in net.parameters() if p.requires_grad]
+        crit(net(images), tg).backward()
+        once = [p.grad.clone() for p in params]
+        bn0 = {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
+        net.load_state_dict(bn0, strict=False)
+        crit(net(images), tg).backward()                      # second pass accumulates into the existing gradients
+        for p, g in zip(params, once):
+            assert torch.equal(p.grad, g + g)
+        prev = ops.set_wgrad_side_stream(False)               # reference: everything on one stream
+        try:
+            for p in params:
+                p.grad = None
+            crit(net(images), tg).backward()
+            serial = [p.grad.clone() for p in params]
+        finally:
+            ops.set_wgrad_side_stream(prev)
+        got = torch.autograd.grad(crit(net(images), tg), params)
+        for a, b, c in zip(once, serial, got):
+            assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def _rccl_worker(rank, world, port, out):
     import os
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
