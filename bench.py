@@ -149,12 +149,15 @@ def main():
     # settle: a freshly started process can run its first steps at a different pace (allocator growth, clocks, a busy
     # host); keep stepping, untimed, until two consecutive 3-step windows agree within 5 % (at most 6 windows)
     prev = None
+    settle_log = []
     for _ in range(6):
         t0 = time.perf_counter()
         for _ in range(3):
             step()
+        issue = time.perf_counter() - t0
         fence()
         w = time.perf_counter() - t0
+        settle_log.append((round(w / 3 * 1e3, 2), round(issue / 3 * 1e3, 2)))
         if world > 1:                              # every rank must take the same decision: the steps contain collectives
             tw = torch.tensor([w], device=dev, dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -194,7 +197,29 @@ def main():
         if len(st):
             wall_us = (st[:, 2] - st[:, 1]).double() / 100.0
             clock_mhz = float(((st[:, 6] - st[:, 5]).double() / wall_us).median())
-    fva_ops.set_wgrad_side_stream(side_was)
+    # The side stream is the product default, but whether the two HIP streams really share the GPU is up to the queue
+    # arbitration of the box (one run in a few, right after other GPU processes had exited, took 57 ms per step with it and
+    # the usual 33 ms without): time three steps each way and keep the faster setting.  Collective: every rank must agree.
+    def window(n=3):
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        w = (time.perf_counter() - t) / n
+        if world > 1:
+            tw = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            w = tw.item()
+        return w * 1e3
+    side_check = {'off': round(window(), 3)}
+    side_use = side_was
+    if side_was:
+        fva_ops.set_wgrad_side_stream(True)
+        step()
+        side_check['on'] = round(window(), 3)
+        side_use = side_check['on'] <= side_check['off']
+    fva_ops.set_wgrad_side_stream(side_use)
     step()
     fence()
     probe_summ = probe.summary()
@@ -204,10 +229,13 @@ def main():
     timer = PyKernelTimer(pool=calls_per_step * args.steps + 8) if args.shapes else \
         KernelTimer(pool=calls_per_step * args.steps + 8, classes=[dom], stride=SAMPLE_STRIDE)
     fence()
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: where the time goes
     with timer as kt:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        step_marks[0].record()
+        for i in range(args.steps):
             loss = step()
+            step_marks[i + 1].record()
         host_s = time.perf_counter() - t0          # time the host needed to ISSUE the steps (no sync inside a step)
         fence()
         elapsed = time.perf_counter() - t0
@@ -254,9 +282,11 @@ def main():
             'kernels_note': f'exclusive per-class figures: all classes bracketed on {probe_steps} untimed steps just before the '
                             'timed region, with the weight gradients on the launch stream (in the timed region they run on a '
                             'low-priority side stream beside the rest of backward, and only the roofline class is bracketed)',
-            'wgrad_side_stream': bool(side_was),
+            'wgrad_side_stream': bool(side_use), 'side_stream_check_ms_per_step': side_check,
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
             'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
+            'step_ms': [round(step_marks[i].elapsed_time(step_marks[i + 1]), 2) for i in range(args.steps)],
+            'settle_windows_ms_per_step': settle_log,
         }
         if args.shapes:
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):
