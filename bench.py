@@ -230,6 +230,21 @@ def main():
         KernelTimer(pool=calls_per_step * args.steps + 8, classes=[dom], stride=SAMPLE_STRIDE)
     fence()
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: where the time goes
+    # Python's cyclic garbage collector: a generation-2 pass over everything this process has built (modules, the oracle's
+    # imports, autograd graphs) stops the launching thread for 0.2-0.3 s -- ten steps' worth of queued GPU work runs dry.
+    # Collect now, then freeze the survivors into the permanent generation so that later passes only look at new objects;
+    # pauses that still happen inside the timed region are recorded.
+    import gc
+    gc_log, gc_t = [], [0.0]
+
+    def gc_watch(phase, info):
+        if phase == 'start':
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append((info['generation'], round((time.perf_counter() - gc_t[0]) * 1e3, 2)))
+    gc.collect()
+    gc.freeze()
+    gc.callbacks.append(gc_watch)
     with timer as kt:
         t0 = time.perf_counter()
         step_marks[0].record()
@@ -239,6 +254,7 @@ def main():
         host_s = time.perf_counter() - t0          # time the host needed to ISSUE the steps (no sync inside a step)
         fence()
         elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(gc_watch)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,6 +303,7 @@ def main():
             'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
             'step_ms': [round(step_marks[i].elapsed_time(step_marks[i + 1]), 2) for i in range(args.steps)],
             'settle_windows_ms_per_step': settle_log,
+            'gc_passes_in_timed_region': [g for g in gc_log if g[1] >= 1.0] or len(gc_log),
         }
         if args.shapes:
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):

@@ -15,6 +15,15 @@ from .checkpoints import SaveModel
 __all__ = ['Fit']
 
 
+def _freeze_garbage_collector():
+    """After the first step everything long-lived exists (modules, optimizer state, the library): collect once and move the
+    survivors to the permanent generation.  A later generation-2 pass over all of it stops the launching thread for
+    0.2-0.3 s -- several steps' worth of queued GPU work -- every few hundred steps (measured in bench.py)."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 class Fit:
     def __init__(self, model, device, optimizer, scheduler, loss, end_epoch, start_epoch=0, train_loader=None, val_loader=None,
                  test_loader=None, data_dict=None, log_every=0, save_last='last.pth'):
@@ -54,6 +63,8 @@ class Fit:
             loss.backward()
             self.optimizer.step()
             losses.append(loss.detach())          # device tensor: no per-step host sync (the reference's tqdm .item() does one)
+            if epoch == self.start_epoch and batch_idx == 0:
+                _freeze_garbage_collector()
             if self.log_every and (batch_idx + 1) % self.log_every == 0:
                 print(f'Epoch {epoch + 1} batch {batch_idx + 1} loss {float(losses[-1])}')
         if self.scheduler is not None:
