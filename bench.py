@@ -274,6 +274,15 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             traffic = (json.load(open(tpath)).get(dom) or {}).get('bytes_per_launch')   # measured offline with PMC counters
+        # north_star's own yardstick: MFMA utilisation on the 3x3 convolutions (exclusive probe figures, all three classes)
+        p3 = probe.summary(ksize=3)
+        f3, t3 = sum(v['flop_total'] for v in p3.values()), sum(v['ms_total'] for v in p3.values())
+        tf3 = f3 / (t3 * 1e-3) / 1e12 if t3 > 0 else 0.0
+        conv3x3 = {'tflops': round(tf3, 2), 'frac_of_peak': round(tf3 / peak, 4), 'ms_per_step': round(t3 / probe_steps, 3),
+                   'frac_at_measured_clock': None if clock_mhz is None else round(tf3 / (peak * clock_mhz / 2400.0), 4),
+                   'per_class_tflops': {k: round(v['tflops'], 2) for k, v in p3.items()},
+                   'note': 'all 3x3 convolution launches of the step (forward, dgrad, wgrad incl. its reduce; thin and stride-2 '
+                           'layers included), exclusive timings of the probe pass'}
         out = {
             'metric': METRIC, 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
@@ -295,6 +304,7 @@ def main():
                                        'convolution launches of one untimed step, of cycle counter / wall clock across the k-loop'},
             'kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / probe_steps, 3),
                             'launches_per_step': v['launches'] // probe_steps} for k, v in probe_summ.items()},
+            'conv3x3': conv3x3,
             'kernels_note': f'exclusive per-class figures: all classes bracketed on {probe_steps} untimed steps just before the '
                             'timed region, with the weight gradients on the launch stream (in the timed region they run on a '
                             'low-priority side stream beside the rest of backward, and only the roofline class is bracketed)',

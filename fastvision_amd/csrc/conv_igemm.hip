@@ -1136,7 +1136,7 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
     p.wt = w_fwd;
     p.out = y;
     p.stats = stats_partial;
-    FvaProfileSpan span(0, 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
 }
 
@@ -1159,7 +1159,7 @@ int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd,
     p.out_img = (OH + 2 * z_pad) * p.out_row;
     p.osy = p.osx = 1;
     p.ooy = p.oox = z_pad;
-    FvaProfileSpan span(0, 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     rc = launch_igemm<EPI_BNACT>(d->dtype, p, (hipStream_t)stream);
     if (rc || z_pad == 0) return rc;
     return fva_zero_halo_border(z, d->B, OH, OW, d->Cout * (d->dtype == FVA_BF16 ? 2 : 4) / 16, z_pad, (hipStream_t)stream);
@@ -1175,7 +1175,7 @@ int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const
     p.wt = w_fwd;
     p.out = out;
     p.bias = bias;
-    FvaProfileSpan span(0, 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     return launch_igemm<EPI_HEAD>(d->dtype, p, (hipStream_t)stream);
 }
 
@@ -1189,7 +1189,7 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
     const int k = d->ksize, s = d->stride, pd = k / 2;
     if (d->dy_pad < pd) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: dy_pad %d < %d", d->dy_pad, pd);
     const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
-    FvaProfileSpan span(1, 2.0 * d->B * OH * OW * (double)d->Cout * d->Cin * k * k, (hipStream_t)stream);
+    FvaProfileSpan span(1 | (k << 8), 2.0 * d->B * OH * OW * (double)d->Cout * d->Cin * k * k, (hipStream_t)stream);
     IgemmParams p = IgemmParams();
     p.in = dy;
     p.wt = w_dgrad;

@@ -608,7 +608,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
     plan_wgrad(d, pl);
-    FvaProfileSpan span(2, 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    FvaProfileSpan span(2 | (d->ksize << 8), 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     const int64_t need = (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
     if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_conv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
     WgradParams p = WgradParams();
@@ -704,7 +704,7 @@ int fva_stem_wgrad_mfma(const void* img4, const void* dy_halo, float* dw_raw, vo
     p.mchunk = mchunk;
     p.tpt = 8;
     p.ngroups = 1;
-    FvaProfileSpan span(2, 2.0 * M * 32.0 * 27.0, (hipStream_t)stream);
+    FvaProfileSpan span(2 | (3 << 8), 2.0 * M * 32.0 * 27.0, (hipStream_t)stream);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(ksplit), dim3(256), 2 * 2 * 64 * 256, s, p);
     FVA_LAUNCH_CHECK("wgrad_kernel");

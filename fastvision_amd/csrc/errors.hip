@@ -15,7 +15,7 @@ int g_stride = 1, g_seen = 0;  // of the eligible calls every g_stride-th is bra
 }  // namespace
 
 FvaProfileSpan::FvaProfileSpan(int cls, double flop, hipStream_t s) : slot(-1), stream(s) {
-    if (!g_on || !((g_mask >> cls) & 1u) || (g_seen++ % g_stride) != 0 || g_used >= (int)g_spans.size()) return;
+    if (!g_on || !((g_mask >> (cls & 0xff)) & 1u) || (g_seen++ % g_stride) != 0 || g_used >= (int)g_spans.size()) return;   // bits 8.. of cls: kernel size
     slot = g_used++;
     g_spans[slot].cls = cls;
     g_spans[slot].flop = flop;

@@ -157,12 +157,17 @@ class KernelTimer:
             cls, flop, ms = (C.c_int32 * n)(), (C.c_double * n)(), (C.c_float * n)()
             got = _lib.load().fva_profile_stop(cls, flop, ms, n)
             _lib.call('fva_profile_classes', 0xffffffff, 1)
-            self.spans = [(self.CLASSES[cls[i]], flop[i], ms[i]) for i in range(got)]
+            self.spans = [(self.CLASSES[cls[i] & 0xff], flop[i], ms[i]) for i in range(got)]
+            self.ksizes = [cls[i] >> 8 for i in range(got)]
         return self.spans
 
-    def summary(self):
+    def summary(self, ksize=None):
+        """ksize: only the launches of layers with that kernel size (3 = the 3x3 convolutions)."""
         out = {}
-        for c, flop, ms in self._collect():
+        spans = self._collect()
+        if ksize is not None:
+            spans = [s for s, k in zip(spans, self.ksizes) if k == ksize]
+        for c, flop, ms in spans:
             s = out.setdefault(c, {'launches': 0, 'ms_total': 0.0, 'flop_total': 0.0})
             s['launches'] += 1
             s['ms_total'] += ms
