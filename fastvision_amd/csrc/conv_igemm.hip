@@ -772,7 +772,7 @@ constexpr int64_t SK_SLAB_BYTES = 512ll * 128 * 4;
 
 // Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, and
 //  * with stream-K enabled (experiment, see streamk_mode): at least 16 k-tile units per CU (any tile count);
-//  * otherwise at least 128 tiles of 256x256 and either a long reduction (>= 24 k-tiles: the per-tile prologue / epilogue
+//  * otherwise at least 128 tiles of 256x256 and either a long reduction (>= 16 k-tiles, FVA_IGEMM8_MINKT: the per-tile prologue / epilogue
 //    is not overlapped by a second block as in the 128x128 kernel) or at most one round of tiles.
 // Measured without stream-K (tools/check_igemm8.py, B = 32): 256->512 @40^2 161 -> 129 us, 512->1024 @20^2 154 -> 118 us,
 // 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.  FVA_IGEMM8=0 turns the kernel off.
@@ -807,7 +807,8 @@ inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in
     if (ktiles > 496 || ktiles < 8) return false;
     if (use_streamk(tiles, ktiles)) return true;
     if (tiles < 128) return false;
-    return ktiles >= 24 || tiles <= 256;
+    static const int min_kt = [] { const char* e = getenv("FVA_IGEMM8_MINKT"); return e ? atoi(e) : 16; }();
+    return ktiles >= min_kt || tiles <= 256;
 }
 
 long long* g_stamps = nullptr;   // fva_conv_debug_stamps
