@@ -107,3 +107,6 @@ struct FvaProfileSpan {
     FvaProfileSpan(int cls, double flop, hipStream_t s);
     ~FvaProfileSpan();
 };
+
+// diagnostic stamp buffer shared by the 8-phase kernels (set by fva_conv_debug_stamps)
+long long* fva_debug_stamps_ptr();

@@ -1040,6 +1040,10 @@ int fva_conv_set_workspace(void* ws, int64_t bytes) {
     return FVA_OK;
 }
 
+}  // extern "C"
+long long* fva_debug_stamps_ptr() { return g_stamps; }
+extern "C" {
+
 int fva_conv_debug_stamps(void* stamps) {
     g_stamps = (long long*)stamps;
     return FVA_OK;

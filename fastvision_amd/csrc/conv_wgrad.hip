@@ -39,6 +39,7 @@ struct WgradParams {
     int ntn, ntc, ksplit, mchunk;
     int tpt, ngroups;  // taps packed side by side in one column tile (thin layers: C < tile), tap groups
     int x_pix_bytes;   // bytes between consecutive pixels of x; 0 = C * sizeof(T) (the stem reads overlapping 4-pixel windows)
+    long long* stamps; // diagnostic (fva_conv_debug_stamps): per block 4 wall-clock + 4 cycle-counter values, 8-phase kernel only
 };
 
 // ds_read_b64_tr_b16 as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever an LDS-DMA
@@ -265,6 +266,13 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
+    auto stamp = [&](int i) {
+        if (p.stamps && tid == 0) {
+            p.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
+            p.stamps[(int64_t)blockIdx.x * 8 + 4 + i] = clock64();
+        }
+    };
+    stamp(0);
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
@@ -416,6 +424,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
         wait_vmcnt_n<0>();
     }
     __builtin_amdgcn_s_barrier();
+    stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
     for (int s = 0; s < steps; ++s) {
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    stamp(2);
 
     // ---- partial tile -> slab[ks][tap][N][C] --------------------------------------------------------------------------
     float* out = p.slab + (int64_t)ks * p.ntaps * p.N * p.C;
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
                 }
             }
         }
+    stamp(3);
 }
 
 // dw[n][c][t] (+)= sum_ks slab[ks][t][n][c].  Block = 64 consecutive (n,c) pairs x 4 split-K groups: every load is
@@ -649,6 +660,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
             (void)hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * 256);
             attr_done = true;
         }
+        p.stamps = fva_debug_stamps_ptr();
         hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
     } else if (d->dtype == FVA_BF16)
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);

@@ -59,5 +59,45 @@ def main():
                   f'second-round starts {np.sort(rel[~first, 0])[:3].round(1).tolist() if (~first).any() else "-"}')
 
 
+def wgrad():
+    lib = _lib.load()
+    dev, dtype = 'cuda:0', torch.bfloat16
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+    for (B, Cin, Cout, H, k) in [(32, 128, 256, 80, 3), (32, 256, 512, 40, 3), (32, 512, 1024, 20, 3)]:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev).to(dtype)
+        dy = torch.randn(B, H + 2, H + 2, Cout, generator=g).to(dev).to(dtype)
+        d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, k, 1, 1, 1)
+        dw = torch.empty(Cout, Cin, k, k, device=dev)
+        wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        st = ops._stream()
+        run = lambda: _lib.call('fva_conv_wgrad', C.byref(d), ops._p(x), ops._p(dy), ops._p(dw), 0, ops._p(ws), wsb, st)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        stamps.zero_()
+        _lib.call('fva_conv_debug_stamps', ops._p(stamps))
+        run()
+        torch.cuda.synchronize()
+        _lib.call('fva_conv_debug_stamps', C.c_void_p(0))
+        raw = stamps.cpu().numpy().reshape(-1, 8)
+        raw = raw[raw[:, 3] > 0]
+        s, cyc = raw[:, :4], raw[:, 4:]
+        rel = (s - s[:, 0].min()) / 100.0
+        pro, loop, epi = rel[:, 1] - rel[:, 0], rel[:, 2] - rel[:, 1], rel[:, 3] - rel[:, 2]
+        mhz = np.median((cyc[:, 2] - cyc[:, 1]) / np.maximum(s[:, 2] - s[:, 1], 1) * 100.0)
+        print(f'wgrad {Cin}->{Cout} @{H}: {len(s)} blocks, call {us:.1f} us (incl. reduce), slab {wsb / 1e6:.0f} MB, clock {mhz:.0f} MHz | '
+              f'last exit {rel[:, 3].max():.1f} us | prologue {np.median(pro):.2f} loop {np.median(loop):.2f} epilogue {np.median(epi):.2f} '
+              f'(max {epi.max():.2f}) us | start spread {rel[:, 0].max():.2f} us')
+
+
 if __name__ == '__main__':
     main()
+    wgrad()
