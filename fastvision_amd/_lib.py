@@ -110,6 +110,8 @@ PROTOTYPES = {
     'fva_nms_candidates_workspace': (_L, [_I, _I]),
     'fva_nms_candidates': (_I, [_P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P]),
     'fva_nms_select_workspace': (_L, [_I, _I]),
+    'fva_roi_align_fwd': (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
 UNCHECKED = {'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',

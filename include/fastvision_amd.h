@@ -348,6 +348,17 @@ int fva_paste_resize_u8(const uint8_t* src, const fva_paste_job* jobs, const int
 int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* ---- RoIAlign (two-stage head) -----------------------------------------------------------------------------
+ * torchvision.ops.roi_align as the reference calls it (demos/faster_rcnn/models/fast.py:227-231,258): rois [K][5] = (batch
+ * index, x1, y1, x2, y2), out [K][C][PH][PW] fp32 (the order torch.flatten(.., 1) feeds the classifier), aligned = False,
+ * sampling_ratio <= 0 = adaptive grid.  feat: halo NHWC [B][H+2*feat_pad][W+2*feat_pad][C] of dtype.  Backward: grad_out in
+ * the same [K][C][PH][PW] layout is scattered (float atomics) into dfeat, dense fp32 NHWC [B][H][W][C], which the caller
+ * zeroes first.  K = 0 is a no-op. */
+int fva_roi_align_fwd(int dtype, const void* feat, int feat_pad, const float* rois, int K, float* out, int B, int H, int W, int C,
+                      int PH, int PW, float spatial_scale, int sampling_ratio, void* stream);
+int fva_roi_align_bwd(const float* grad_out, const float* rois, int K, float* dfeat, int B, int H, int W, int C, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
