@@ -416,3 +416,45 @@ extern "C" int fva_nms_select(const void* cand, const int32_t* counts, int32_t B
     FVA_LAUNCH_CHECK("nms_scan_kernel");
     return FVA_OK;
 }
+
+// ---- RPN proposal rows (demos/faster_rcnn/models/rpn.py:110-186) ---------------------------------------------
+// filter_proposals up to the per-image top-k: decode the regression against the anchor grid, objectness = softmax over the two
+// logits, xywh -> xyxy, clamp to the feature map.  One row per (y, x, a) in the reference's view(bs, -1, 5) order, laid out as
+// the NMS stage expects them: x1, y1, x2, y2, score, 1.0.  Quirk kept: BOTH extents use exp(d[2]) (rpn.py:118-119).
+namespace {
+__global__ __launch_bounds__(256) void rpn_decode_kernel(const float* __restrict__ cls, const float* __restrict__ d,
+                                                         const float* __restrict__ anchors, float* __restrict__ out, int B, int H, int W,
+                                                         int A) {
+    const int64_t n = (int64_t)B * H * W * A;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int a = (int)(i % A);
+        const int64_t cell = i / A;
+        const int x = (int)(cell % W), y = (int)((cell / W) % H);
+        const float aw = anchors[2 * a], ah = anchors[2 * a + 1];
+        const float4 t = *(const float4*)(d + i * 4);
+        const float2 c = *(const float2*)(cls + i * 2);
+        const float xc = t.x * aw + (float)x, yc = t.y * ah + (float)y;
+        const float e = expf(t.z);
+        const float w = e * aw, h = e * ah;
+        const float m = fmaxf(c.x, c.y), e0 = expf(c.x - m), e1 = expf(c.y - m);
+        float* o = out + i * 6;
+        o[0] = clampf(xc - w / 2.f, 0.f, (float)(W - 1));
+        o[1] = clampf(yc - h / 2.f, 0.f, (float)(H - 1));
+        o[2] = clampf(xc + w / 2.f, 0.f, (float)(W - 1));
+        o[3] = clampf(yc + h / 2.f, 0.f, (float)(H - 1));
+        o[4] = e1 / (e0 + e1);
+        o[5] = 1.f;
+    }
+}
+}  // namespace
+
+extern "C" int fva_rpn_decode(const float* cls, const float* deltas, const float* anchors_wh, float* out, int32_t B, int32_t H, int32_t W,
+                              int32_t A, void* stream) {
+    if (!cls || !deltas || !anchors_wh || !out || B <= 0 || H <= 0 || W <= 0 || A <= 0) return fva_fail(FVA_ERR_ARG, "fva_rpn_decode: bad argument");
+    const int64_t n = (int64_t)B * H * W * A;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, cls, deltas,
+                       anchors_wh, out, B, H, W, A);
+    FVA_LAUNCH_CHECK("rpn_decode_kernel");
+    return FVA_OK;
+}

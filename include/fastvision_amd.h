@@ -348,6 +348,14 @@ int fva_paste_resize_u8(const uint8_t* src, const fva_paste_job* jobs, const int
 int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* ---- RPN proposal rows (two-stage head) ------------------------------------------------------------------------
+ * filter_proposals of demos/faster_rcnn/models/rpn.py:162-186 up to the per-image selection: cls [B][H][W][A][2] logits,
+ * deltas [B][H][W][A][4], anchors_wh [A][2] (already divided by the backbone stride; anchor centres are the cell indices) ->
+ * out [B][H*W*A][6] = clamped x1, y1, x2, y2, softmax foreground score, 1.0: the rows fva_nms_candidates / fva_nms_select
+ * take (box_mode 1, score_mode 1, max_nms = rpn_pre_nms_top_n, max_det = rpn_post_nms_top_n). */
+int fva_rpn_decode(const float* cls, const float* deltas, const float* anchors_wh, float* out, int32_t B, int32_t H, int32_t W,
+                   int32_t A, void* stream);
+
 /* ---- RoIAlign (two-stage head) -----------------------------------------------------------------------------
  * torchvision.ops.roi_align as the reference calls it (demos/faster_rcnn/models/fast.py:227-231,258): rois [K][5] = (batch
  * index, x1, y1, x2, y2), out [K][C][PH][PW] fp32 (the order torch.flatten(.., 1) feeds the classifier), aligned = False,

@@ -11,6 +11,7 @@ integer ``clamp_`` bound).  No reference source is copied: the fixtures are inpu
                                           # top-level ``utils``/``models`` names clash with nothing else then
     python oracle/make_golden.py eval_lib / eval_demo   # validation side (decode, NMS wrappers, mAP): scope row f-2
     python oracle/make_golden.py pipeline / pipeline_demo   # input side (resize, pad, flips, normalise, labels): row f-3
+    python oracle/make_golden.py rpn      # two-stage head, RPN proposal layer: row f-4
     python oracle/make_golden.py all      # everything, one child process per surface
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
@@ -690,6 +691,41 @@ def gen_pipeline_demo():
     print('pipeline_demo fixtures:', len(out), 'arrays')
 
 
+# ====================================================================================== two-stage head (scope row f-4)
+def gen_rpn():
+    """RPN proposal layer: the reference's own RPN class (demos/faster_rcnn/models/rpn.py) on random head outputs.  Captured:
+    the inputs, the rows right after the clamp (by re-running its helper methods exactly as filter_proposals does) and the
+    per-image proposals of filter_proposals itself (torchvision.ops.nms = the oracle's stand-in)."""
+    import torch
+    _stub_missing()
+    _install_nms()
+    sys.path.insert(0, os.path.join(REF, 'demos', 'faster_rcnn'))
+    from models.rpn import RPN
+    from utils.anchor_generator import get_base_anchor
+    out = {}
+    for case, (B, H, W, pre, post, scale) in enumerate([(2, 14, 14, 2000, 2000, 1.0), (1, 19, 25, 300, 50, 2.0), (3, 7, 9, 2000, 2000, 0.3)]):
+        base = torch.from_numpy(get_base_anchor(scales=[128, 256, 512], ratios=[0.5, 1, 2]))
+        rpn = RPN(training=False, base_anchors=base, backbone_stride=16, in_channels=8, rpn_pre_nms_top_n=pre, rpn_post_nms_top_n=post,
+                  rpn_nms_thresh=0.7)
+        g = torch.Generator().manual_seed(100 + case)
+        A = base.size(0)
+        cls = torch.randn(B, H, W, A, 2, generator=g) * 2
+        d = torch.randn(B, H, W, A, 4, generator=g) * scale
+        anchors = rpn.make_anchors_xywh(H, W, 'cpu')
+        props = rpn.filter_proposals(cls, d, anchors, H, W)
+        out[f'c{case}_shape'] = np.array([B, H, W, A, pre, post])
+        out[f'c{case}_cls'], out[f'c{case}_d'] = cls.numpy(), d.numpy()
+        out[f'c{case}_base_wh'] = rpn.base_anchors.numpy()
+        out[f'c{case}_anchors'] = anchors.numpy()
+        xyxy = rpn.xywh2xyxy(rpn.dxdydwdh2xywh(d.clone(), anchors))
+        out[f'c{case}_xyxy_unclamped'] = xyxy.numpy()
+        out[f'c{case}_score'] = torch.softmax(cls.clone(), dim=4)[..., 1].numpy()
+        for b, p in enumerate(props):
+            out[f'c{case}_prop{b}'] = p.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'rpn_proposals.npz'), **out)
+    print('rpn fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_proposals.npz')), 'bytes')
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLD, exist_ok=True)
@@ -705,7 +741,9 @@ if __name__ == '__main__':
         gen_pipeline()
     elif which == 'pipeline_demo':
         gen_pipeline_demo()
+    elif which == 'rpn':
+        gen_rpn()
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for s in ('lib', 'demo', 'eval_lib', 'eval_demo', 'pipeline', 'pipeline_demo'):
+        for s in ('lib', 'demo', 'eval_lib', 'eval_demo', 'pipeline', 'pipeline_demo', 'rpn'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s], env=env)

@@ -1,0 +1,58 @@
+"""CPU restatement of the RPN proposal layer (scope row f-4): demos/faster_rcnn/models/rpn.py:110-186 (`dxdydwdh2xywh`,
+`xywh2xyxy`, `make_anchors_xywh`, `filter_proposals`).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Parity status: everything up to and including the per-image top-k is PINNED by tests/golden/rpn_proposals.npz, captured from
+the reference's own RPN class run in the build container (oracle/make_golden.py rpn); `torchvision.ops.nms` underneath it is
+absent from this image -> the golden run used oracle.detect.nms as its stand-in (parity unpinned for the suppression itself,
+as for row f-2).  Quirk restated on purpose: both extents are decoded with exp(d[..., 2]) (rpn.py:118-119).
+"""
+import numpy as np
+import torch
+
+from .detect import nms
+
+
+def make_anchors_xywh(base_anchors_wh, height, width):
+    """rpn.py:147-160: anchor centres are the integer cell coordinates (x, y); wh = base anchors / stride. -> [1,H,W,A,4]"""
+    a = torch.as_tensor(base_anchors_wh, dtype=torch.float32)
+    A = a.shape[0]
+    ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing='ij')
+    xy = torch.stack([xs, ys], dim=-1).float().view(1, height, width, 1, 2).expand(1, height, width, A, 2)
+    wh = a.view(1, 1, 1, A, 2).expand(1, height, width, A, 2)
+    return torch.cat([xy, wh], dim=4)
+
+
+def proposal_rows(cls, dxdydwdh, anchor_xywh, height, width):
+    """rpn.py:162-180: [B, H*W*A, 5] = score, clamped x1, y1, x2, y2"""
+    xywh = dxdydwdh.clone()
+    xywh[..., 0] = dxdydwdh[..., 0] * anchor_xywh[..., 2] + anchor_xywh[..., 0]
+    xywh[..., 1] = dxdydwdh[..., 1] * anchor_xywh[..., 3] + anchor_xywh[..., 1]
+    xywh[..., 2] = torch.exp(dxdydwdh[..., 2]) * anchor_xywh[..., 2]
+    xywh[..., 3] = torch.exp(dxdydwdh[..., 2]) * anchor_xywh[..., 3]
+    score = torch.softmax(cls, dim=4)[..., 1]
+    rows = torch.cat([score[..., None], xywh], dim=4).view(cls.size(0), -1, 5)
+    x, y, w, h = rows[..., 1].clone(), rows[..., 2].clone(), rows[..., 3].clone(), rows[..., 4].clone()
+    rows[..., 1] = (x - w / 2).clamp(min=0, max=width - 1)
+    rows[..., 2] = (y - h / 2).clamp(min=0, max=height - 1)
+    rows[..., 3] = (x + w / 2).clamp(min=0, max=width - 1)
+    rows[..., 4] = (y + h / 2).clamp(min=0, max=height - 1)
+    return rows
+
+
+def filter_proposals(cls, dxdydwdh, base_anchors_wh, pre_nms_top_n=2000, post_nms_top_n=2000, nms_thresh=0.7):
+    """rpn.py:162-209 -> list over images of [n, 4] xywh (feature-map cells), best score first"""
+    B, H, W = cls.shape[:3]
+    rows = proposal_rows(cls.float(), dxdydwdh.float(), make_anchors_xywh(base_anchors_wh, H, W), H, W)
+    out = []
+    for b in range(B):
+        p = rows[b]
+        _, idx = p[:, 0].topk(min(pre_nms_top_n, p.size(0)))
+        p = p[idx]
+        keep = nms(p[:, 1:], p[:, 0], nms_thresh)[:post_nms_top_n]
+        p = p[keep]
+        xyxy = p[:, 1:]
+        out.append(torch.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0],
+                                xyxy[:, 3] - xyxy[:, 1]], dim=1))
+    return out

@@ -1,0 +1,59 @@
+"""RPN proposal layer on the HIP kernels (scope row f-4) against the reference's vectors (tests/golden/rpn_proposals.npz) and
+the CPU restatement, through the C ABI (fastvision_amd.rpn_ops)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_proposals.npz'))
+CASES = sorted({k.split('_')[0] for k in GOLD.files})
+
+
+@pytest.mark.parametrize('c', CASES)
+def test_rows_and_proposals_match_reference(c):
+    from fastvision_amd.rpn_ops import filter_proposals, rpn_proposal_rows
+    B, H, W, A, pre, post = (int(v) for v in GOLD[f'{c}_shape'])
+    cls = torch.from_numpy(GOLD[f'{c}_cls']).to(DEV)
+    d = torch.from_numpy(GOLD[f'{c}_d']).to(DEV)
+    rows = rpn_proposal_rows(cls, d, GOLD[f'{c}_base_wh']).cpu()
+    assert tuple(rows.shape) == (B, H * W * A, 6)
+    un = torch.from_numpy(GOLD[f'{c}_xyxy_unclamped']).view(B, -1, 4)
+    lim = torch.tensor([W - 1, H - 1, W - 1, H - 1], dtype=torch.float32)
+    want_box = torch.minimum(un.clamp(min=0), lim)
+    # exp / softmax run in the device's libm: boxes to 1e-5 relative, scores to 1e-6 absolute; the clamp bounds exactly
+    assert torch.allclose(rows[..., :4], want_box, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rows[..., 4], torch.from_numpy(GOLD[f'{c}_score']).view(B, -1), rtol=0, atol=1e-6)
+    assert torch.all(rows[..., 5] == 1)
+    props = filter_proposals(cls, d, GOLD[f'{c}_base_wh'], pre, post, 0.7)
+    assert len(props) == B
+    for b, p in enumerate(props):
+        want = torch.from_numpy(GOLD[f'{c}_prop{b}'])
+        assert p.shape == want.shape, (p.shape, want.shape)
+        assert torch.allclose(p.cpu(), want, rtol=1e-5, atol=1e-4)
+
+
+def test_reference_size_properties():
+    """VGG16 stride-16 map of an 800x608 image (38 x 50 cells, 9 anchors = 17100 rows per image), 4 images, the reference's
+    defaults (2000 / 2000 / 0.7): sizes, ordering and the NMS invariant (no kept pair overlaps by more than the threshold)."""
+    from fastvision_amd.rpn_ops import filter_proposals
+    from oracle.detect import iou_xyxy_batch
+    g = torch.Generator().manual_seed(7)
+    B, H, W, A = 4, 38, 50, 9
+    cls = (torch.randn(B, H, W, A, 2, generator=g) * 2).to(DEV)
+    d = (torch.randn(B, H, W, A, 4, generator=g) * 0.5).to(DEV)
+    base = torch.tensor([[11.3, 5.7], [22.6, 11.3], [45.3, 22.6], [8, 8], [16, 16], [32, 32], [5.7, 11.3], [11.3, 22.6], [22.6, 45.3]])
+    props = filter_proposals(cls, d, base, 2000, 2000, 0.7)
+    assert len(props) == B
+    for p in props:
+        n = p.size(0)
+        assert 0 < n <= 2000 and p.size(1) == 4
+        assert torch.all(p[:, 2] >= 0) and torch.all(p[:, 3] >= 0)
+        xyxy = torch.stack([p[:, 0] - p[:, 2] / 2, p[:, 1] - p[:, 3] / 2, p[:, 0] + p[:, 2] / 2, p[:, 1] + p[:, 3] / 2], 1).cpu()
+        assert xyxy.min() >= -1e-4 and xyxy[:, [0, 2]].max() <= W - 1 + 1e-4 and xyxy[:, [1, 3]].max() <= H - 1 + 1e-4
+        iou = torch.as_tensor(iou_xyxy_batch(xyxy[:400], xyxy[:400]))
+        iou = torch.nan_to_num(iou, nan=0.0)
+        iou.fill_diagonal_(0)
+        assert iou.max() <= 0.7 + 1e-5
