@@ -458,3 +458,104 @@ extern "C" int fva_rpn_decode(const float* cls, const float* deltas, const float
     FVA_LAUNCH_CHECK("rpn_decode_kernel");
     return FVA_OK;
 }
+
+// ---- RPN anchor / ground-truth matcher (demos/faster_rcnn/models/rpn.py:209-277) ------------------------------
+// Per image: IoU of every anchor (xywh, feature cells) with every ground-truth box of that image (normalised xywh scaled by the
+// map size), then the reference's labelling: label = index of the best box if its IoU > pos_thr, -1 (negative) if the best IoU <
+// neg_thr, -2 (ignored) otherwise; finally every box claims the anchor it overlaps most, in box order (a later box overrides
+// an earlier one on the same anchor).  Index work: bit-exact with the reference -- same fp32 expression order (this file is
+// built with -ffp-contract=off), first maximum wins (torch.max).
+namespace {
+__device__ __forceinline__ float rpn_iou(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh) {
+    const float ax1 = ax - aw / 2.f, ay1 = ay - ah / 2.f, ax2 = ax + aw / 2.f, ay2 = ay + ah / 2.f;
+    const float bx1 = bx - bw / 2.f, by1 = by - bh / 2.f, bx2 = bx + bw / 2.f, by2 = by + bh / 2.f;
+    const float area1 = (ax2 - ax1) * (ay2 - ay1), area2 = (bx2 - bx1) * (by2 - by1);
+    const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+    const float inter = iw * ih;
+    const float uni = area1 + area2 - inter + 1e-7f;
+    return inter / uni;
+}
+
+// labels of phase 1: one thread per (image, anchor); the image's boxes are the rows of targets with column 0 == image
+__global__ __launch_bounds__(256) void rpn_label_kernel(const float* __restrict__ anchors, int Na, const float* __restrict__ targets, int T,
+                                                        float fw, float fh, float pos_thr, float neg_thr, int32_t* __restrict__ labels) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= Na) return;
+    const float4 an = *(const float4*)(anchors + (int64_t)a * 4);
+    float best = -INFINITY;
+    int best_t = 0, local = 0;
+    for (int t = 0; t < T; ++t) {
+        const float* tg = targets + (int64_t)t * 6;
+        if (tg[0] != (float)b) continue;
+        const float v = rpn_iou(an.x, an.y, an.z, an.w, tg[2] * fw, tg[3] * fh, tg[4] * fw, tg[5] * fh);
+        if (v > best) { best = v; best_t = local; }
+        ++local;
+    }
+    int lab = -2;
+    if (local > 0) {
+        if (best > pos_thr) lab = best_t;
+        if (best < neg_thr) lab = -1;          // the reference applies this test second: it wins when both hold
+    }
+    labels[(int64_t)b * Na + a] = lab;
+}
+
+// phase 2: one block per (box row): arg-max of its IoU over the anchors (first maximum), wave shuffles + LDS
+__global__ __launch_bounds__(256) void rpn_best_anchor_kernel(const float* __restrict__ anchors, int Na, const float* __restrict__ targets,
+                                                              float fw, float fh, int32_t* __restrict__ best_anchor) {
+    const int t = blockIdx.x;
+    const float* tg = targets + (int64_t)t * 6;
+    const float bx = tg[2] * fw, by = tg[3] * fh, bw = tg[4] * fw, bh = tg[5] * fh;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int a = threadIdx.x; a < Na; a += 256) {
+        const float4 an = *(const float4*)(anchors + (int64_t)a * 4);
+        const float v = rpn_iou(an.x, an.y, an.z, an.w, bx, by, bw, bh);
+        if (v > best) { best = v; idx = a; }     // ascending a per thread: keeps the first maximum
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < idx)) { best = sv[w]; idx = si[w]; }
+        best_anchor[t] = idx;
+    }
+}
+
+// phase 3: per image, in box order: labels[best_anchor[box]] = local index of the box
+__global__ void rpn_claim_kernel(const float* __restrict__ targets, int T, const int32_t* __restrict__ best_anchor, int Na,
+                                 int32_t* __restrict__ labels) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int local = 0;
+    for (int t = 0; t < T; ++t) {
+        if (targets[(int64_t)t * 6] != (float)b) continue;
+        labels[(int64_t)b * Na + best_anchor[t]] = local;
+        ++local;
+    }
+}
+}  // namespace
+
+extern "C" int fva_rpn_match(const float* anchors_xywh, int32_t Na, const float* targets, int32_t T, int32_t B, int32_t feature_h,
+                             int32_t feature_w, float pos_thr, float neg_thr, int32_t* labels, int32_t* workspace, void* stream) {
+    if (!anchors_xywh || !labels || Na <= 0 || B <= 0 || T < 0 || (T > 0 && (!targets || !workspace)))
+        return fva_fail(FVA_ERR_ARG, "fva_rpn_match: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rpn_label_kernel, dim3(cdiv(Na, 256), B), dim3(256), 0, s, anchors_xywh, Na, targets, T, (float)feature_w, (float)feature_h,
+                       pos_thr, neg_thr, labels);
+    FVA_LAUNCH_CHECK("rpn_label_kernel");
+    if (T > 0) {
+        hipLaunchKernelGGL(rpn_best_anchor_kernel, dim3(T), dim3(256), 0, s, anchors_xywh, Na, targets, (float)feature_w, (float)feature_h, workspace);
+        FVA_LAUNCH_CHECK("rpn_best_anchor_kernel");
+        hipLaunchKernelGGL(rpn_claim_kernel, dim3(B), dim3(64), 0, s, targets, T, workspace, Na, labels);
+        FVA_LAUNCH_CHECK("rpn_claim_kernel");
+    }
+    return FVA_OK;
+}

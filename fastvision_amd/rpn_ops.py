@@ -11,7 +11,7 @@ from . import _lib
 from .detect_ops import nms_batch
 from .ops import _p, _stream, require_gpu
 
-__all__ = ['filter_proposals', 'rpn_proposal_rows']
+__all__ = ['filter_proposals', 'rpn_proposal_rows', 'rpn_match', 'rpn_sample']
 
 _MODE = dict(box_mode=1, score_mode=1, rethreshold=0, class_gap=0.0)
 
@@ -41,3 +41,30 @@ def filter_proposals(cls, dxdydwdh, base_anchors_wh, pre_nms_top_n=2000, post_nm
         out.append(torch.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0],
                                 xyxy[:, 3] - xyxy[:, 1]], dim=1))
     return out
+
+
+def rpn_match(anchor_xywh, targets, batch, feature_height, feature_width, pos_thr=0.7, neg_thr=0.3):
+    """The anchor labelling of RPN.computet_loss (rpn.py:255-277) on the device: anchor_xywh [.., 4] (make_anchors_xywh),
+    targets [T, 6] = image index, class, normalised xywh -> [B, Na] int64: >= 0 index of the matched box among its image's
+    boxes, -1 negative, -2 ignored."""
+    require_gpu(anchor_xywh, 'rpn_match')
+    anchors = anchor_xywh.detach().reshape(-1, 4).float().contiguous()
+    tg = targets.detach().to(device=anchors.device, dtype=torch.float32).contiguous()
+    Na, T = anchors.size(0), tg.size(0)
+    labels = torch.empty((batch, Na), dtype=torch.int32, device=anchors.device)
+    ws = torch.empty(max(T, 1), dtype=torch.int32, device=anchors.device)
+    _lib.call('fva_rpn_match', _p(anchors), Na, _p(tg) if T else None, T, batch, int(feature_height), int(feature_width),
+              float(pos_thr), float(neg_thr), _p(labels), _p(ws), _stream())
+    return labels.long()
+
+
+def rpn_sample(labels_image, positives_per_image=128, negatives_per_image=128, perm_pos=None, perm_neg=None):
+    """rpn.py:279-290 for one image's labels: indices of the sampled positive / negative anchors (torch.randperm draws unless
+    the permutations are given)."""
+    pos = torch.nonzero(labels_image >= 0).flatten()
+    neg = torch.nonzero(labels_image == -1).flatten()
+    n_pos = min(pos.numel(), positives_per_image)
+    n_neg = min(neg.numel(), max(negatives_per_image, positives_per_image + negatives_per_image - n_pos))
+    perm_pos = torch.randperm(pos.numel(), device=labels_image.device) if perm_pos is None else perm_pos
+    perm_neg = torch.randperm(neg.numel(), device=labels_image.device) if perm_neg is None else perm_neg
+    return pos[perm_pos[:n_pos]], neg[perm_neg[:n_neg]]

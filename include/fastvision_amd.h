@@ -356,6 +356,14 @@ int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int6
 int fva_rpn_decode(const float* cls, const float* deltas, const float* anchors_wh, float* out, int32_t B, int32_t H, int32_t W,
                    int32_t A, void* stream);
 
+/* RPN anchor / ground-truth matcher: the labelling inside RPN.computet_loss (demos/faster_rcnn/models/rpn.py:209-277).
+ * anchors_xywh [Na][4] in feature cells (make_anchors_xywh, flattened (y, x, a)); targets [T][6] = image index, class, normalised
+ * xywh (scaled by the map size here, rpn.py:257).  labels [B][Na] i32: >= 0 index of the matched box WITHIN its image's boxes,
+ * -1 negative (best IoU < neg_thr), -2 ignored; every box then claims its best anchor, later boxes overriding earlier ones.
+ * An image without boxes gets -2 everywhere.  workspace: T int32 (best anchor per box row). */
+int fva_rpn_match(const float* anchors_xywh, int32_t Na, const float* targets, int32_t T, int32_t B, int32_t feature_h,
+                  int32_t feature_w, float pos_thr, float neg_thr, int32_t* labels, int32_t* workspace, void* stream);
+
 /* ---- RoIAlign (two-stage head) -----------------------------------------------------------------------------
  * torchvision.ops.roi_align as the reference calls it (demos/faster_rcnn/models/fast.py:227-231,258): rois [K][5] = (batch
  * index, x1, y1, x2, y2), out [K][C][PH][PW] fp32 (the order torch.flatten(.., 1) feeds the classifier), aligned = False,

@@ -723,7 +723,66 @@ def gen_rpn():
         for b, p in enumerate(props):
             out[f'c{case}_prop{b}'] = p.numpy()
     np.savez_compressed(os.path.join(GOLD, 'rpn_proposals.npz'), **out)
+    gen_rpn_match(RPN, get_base_anchor)
     print('rpn fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_proposals.npz')), 'bytes')
+
+
+def gen_rpn_match(RPN, get_base_anchor):
+    """The labelling inside RPN.computet_loss is not returned by anything, so the reference is made to reveal it: the class
+    logits fed to it carry (anchor index, image index) instead of scores, the regression carries the anchor index, torch.randperm
+    is the identity and the per-image sample sizes are unbounded.  The tensors the reference then hands to its two loss
+    functions list, per image, every negative anchor followed by every positive anchor (classification) and, for the positive
+    ones, the regression targets computed from the box each was matched with."""
+    import torch
+    import torch.nn.functional as F
+    import models.rpn as M
+    out = {}
+    for case, (B, H, W, T) in enumerate([(2, 14, 14, 9), (3, 19, 25, 31), (1, 7, 9, 2)]):
+        base = torch.from_numpy(get_base_anchor(scales=[128, 256, 512], ratios=[0.5, 1, 2]))
+        rpn = RPN(training=True, base_anchors=base, backbone_stride=16, in_channels=8, rpn_positives_per_image=10 ** 7,
+                  rpn_negatives_per_image=10 ** 7)
+        A = base.size(0)
+        Na = H * W * A
+        g = torch.Generator().manual_seed(500 + case)
+        tb = torch.sort(torch.randint(0, B, (T,), generator=g))[0].float()
+        tb[:B] = torch.arange(B).float()                      # every image has at least one box (the reference needs it)
+        tb = torch.sort(tb)[0]
+        wh = torch.exp(np.log(0.05) + (np.log(0.9) - np.log(0.05)) * torch.rand(T, 2, generator=g))
+        xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+        targets = torch.cat([tb[:, None], torch.randint(0, 20, (T, 1), generator=g).float(), xy, wh], 1)
+        if T > 4:                                             # a box identical to an anchor (IoU 1) and a tiny one (claims by rule 3 only)
+            targets[2, 2:] = torch.tensor([5.0 / W, 4.0 / H, float(rpn.base_anchors[4, 0]) / W, float(rpn.base_anchors[4, 1]) / H])
+            targets[3, 4:] = torch.tensor([0.004, 0.003])
+        idx = torch.arange(Na, dtype=torch.float32).view(1, H, W, A, 1).expand(B, H, W, A, 1)
+        img = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1, 1).expand(B, H, W, A, 1)
+        cls = torch.cat([idx, img], 4).contiguous()
+        d = idx.expand(B, H, W, A, 4).contiguous()
+        anchors = rpn.make_anchors_xywh(H, W, 'cpu')
+        seen = {}
+        class Capture(torch.nn.Module):
+            def forward(self, p, t):
+                seen['cls'] = (p.clone(), t.clone())
+                return p.sum() * 0
+        rpn.focal_loss = Capture()
+        real_sl1, real_perm = F.smooth_l1_loss, torch.randperm
+        F.smooth_l1_loss = lambda p, t, reduction='mean': (seen.__setitem__('box', (p.clone(), t.clone())), p.sum() * 0)[1]
+        torch.randperm = lambda n, device=None: torch.arange(n)
+        try:
+            rpn.computet_loss(cls, d, anchors, targets)
+        finally:
+            F.smooth_l1_loss, torch.randperm = real_sl1, real_perm
+        pc, tc = seen['cls']
+        pb, tbx = seen['box']
+        out[f'm{case}_shape'] = np.array([B, H, W, A, T])
+        out[f'm{case}_base_wh'] = rpn.base_anchors.numpy()
+        out[f'm{case}_targets'] = targets.numpy()
+        out[f'm{case}_anchor'] = pc[:, 0].long().numpy()           # sampled anchors: per image negatives then positives
+        out[f'm{case}_image'] = pc[:, 1].long().numpy()
+        out[f'm{case}_is_pos'] = tc.long().numpy()
+        out[f'm{case}_pos_anchor'] = pb[:, 0].long().numpy()       # positives again, image after image
+        out[f'm{case}_pos_dxdydwdh'] = tbx.numpy()                 # xywh2dxdydwdh(matched box, anchor)
+    np.savez_compressed(os.path.join(GOLD, 'rpn_match.npz'), **out)
+    print('rpn match fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_match.npz')), 'bytes')
 
 
 if __name__ == '__main__':

@@ -56,3 +56,57 @@ def filter_proposals(cls, dxdydwdh, base_anchors_wh, pre_nms_top_n=2000, post_nm
         out.append(torch.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0],
                                 xyxy[:, 3] - xyxy[:, 1]], dim=1))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ matcher (rpn.py:209-290)
+def batch_iou(xywh1, xywh2, eps=1e-7):
+    """rpn.py:209-226: [N,4] x [M,4] (xywh) -> [N,M]"""
+    def xyxy(b):
+        return torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
+    a, b = xyxy(xywh1), xyxy(xywh2)
+    area1 = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area2 = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    inter = (torch.minimum(a[:, None, 2], b[:, 2]) - torch.maximum(a[:, None, 0], b[:, 0])).clamp(0) * \
+            (torch.minimum(a[:, None, 3], b[:, 3]) - torch.maximum(a[:, None, 1], b[:, 1])).clamp(0)
+    union = area1[:, None] + area2 - inter + eps
+    return inter / union
+
+
+def rpn_match(anchor_xywh, targets, batch, feature_height, feature_width, pos_thr=0.7, neg_thr=0.3):
+    """The labelling inside computet_loss (rpn.py:255-277): [B, Na] int64 -- >= 0: index of the matched box among the image's
+    boxes, -1 negative, -2 ignored.  (An image without boxes makes the reference raise; here it is all -2.)"""
+    anchors = anchor_xywh.reshape(-1, 4).float()
+    out = torch.full((batch, anchors.size(0)), -2, dtype=torch.int64)
+    scale = torch.tensor([feature_width, feature_height, feature_width, feature_height])
+    for b in range(batch):
+        tg = targets[targets[:, 0] == b]
+        if tg.size(0) == 0:
+            continue
+        iou = batch_iou(anchors, tg[:, 2:] * scale)
+        best, idx = torch.max(iou, dim=1)
+        lab = out[b]
+        m = best > pos_thr
+        lab[m] = idx[m]
+        lab[best < neg_thr] = -1
+        _, best_anchor = torch.max(iou, dim=0)
+        for t in range(best_anchor.size(0)):
+            lab[best_anchor[t]] = t
+    return out
+
+
+def rpn_sample(labels_image, positives_per_image=128, negatives_per_image=128, perm_pos=None, perm_neg=None):
+    """rpn.py:279-290 for one image: indices of the sampled positive and negative anchors.  perm_*: the permutations the
+    reference draws with torch.randperm (injectable so that the draw can be shared with the path under test)."""
+    pos = torch.nonzero(labels_image >= 0).flatten()
+    neg = torch.nonzero(labels_image == -1).flatten()
+    n_pos = min(pos.numel(), positives_per_image)
+    n_neg = min(neg.numel(), max(negatives_per_image, positives_per_image + negatives_per_image - n_pos))
+    perm_pos = torch.randperm(pos.numel()) if perm_pos is None else perm_pos
+    perm_neg = torch.randperm(neg.numel()) if perm_neg is None else perm_neg
+    return pos[perm_pos[:n_pos]], neg[perm_neg[:n_neg]]
+
+
+def xywh2dxdydwdh(target_xywh, anchor_xywh, eps=1e-7):
+    """rpn.py:123-131: regression targets of matched (box, anchor) pairs"""
+    return torch.stack([(target_xywh[:, 0] - anchor_xywh[:, 0]) / anchor_xywh[:, 2], (target_xywh[:, 1] - anchor_xywh[:, 1]) / anchor_xywh[:, 3],
+                        torch.log(target_xywh[:, 2] / anchor_xywh[:, 2] + eps), torch.log(target_xywh[:, 3] / anchor_xywh[:, 3] + eps)], 1)

@@ -57,3 +57,48 @@ def test_reference_size_properties():
         iou = torch.nan_to_num(iou, nan=0.0)
         iou.fill_diagonal_(0)
         assert iou.max() <= 0.7 + 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ matcher (index work: bit-exact)
+from tests.test_oracle_rpn_golden import MATCH, MCASES, check_labels_against_reference  # noqa: E402
+
+
+@pytest.mark.parametrize('c', MCASES)
+def test_matcher_labels_equal_reference(c):
+    from fastvision_amd.rpn_ops import rpn_match
+    from oracle import rpn as R
+    B, H, W, A, T = (int(v) for v in MATCH[f'{c}_shape'])
+    anchors = R.make_anchors_xywh(MATCH[f'{c}_base_wh'], H, W)
+    targets = torch.from_numpy(MATCH[f'{c}_targets'])
+    labels = rpn_match(anchors.to(DEV), targets.to(DEV), B, H, W).cpu()
+    assert labels.dtype == torch.int64 and tuple(labels.shape) == (B, H * W * A)
+    check_labels_against_reference(c, labels)
+    assert torch.equal(labels, R.rpn_match(anchors, targets, B, H, W))
+
+
+def test_matcher_full_size_equals_oracle_and_edge_cases():
+    """4 images of a 38 x 50 map with 9 anchors (17100 per image), 57 boxes incl. duplicates and boxes that overlap nothing."""
+    from fastvision_amd.rpn_ops import rpn_match, rpn_sample
+    from oracle import rpn as R
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 4, 38, 50
+    base = torch.tensor([[11.3, 5.7], [22.6, 11.3], [45.3, 22.6], [8, 8], [16, 16], [32, 32], [5.7, 11.3], [11.3, 22.6], [22.6, 45.3]])
+    anchors = R.make_anchors_xywh(base, H, W)
+    T = 57
+    tb = torch.sort(torch.randint(0, B, (T,), generator=g))[0].float()
+    wh = torch.exp(np.log(0.02) + (np.log(0.95) - np.log(0.02)) * torch.rand(T, 2, generator=g))
+    xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+    targets = torch.cat([tb[:, None], torch.zeros(T, 1), xy, wh], 1)
+    targets[5] = targets[4]                                   # a duplicated box: the later one claims the shared best anchor
+    targets[9, 2:] = torch.tensor([0.5, 0.5, 1e-4, 1e-4])    # overlaps (almost) nothing: still claims an anchor
+    want = R.rpn_match(anchors, targets, B, H, W)
+    got = rpn_match(anchors.to(DEV), targets.to(DEV), B, H, W)
+    assert torch.equal(got.cpu(), want)
+    # an image without boxes (the reference raises there): ignored everywhere; and no boxes at all
+    only0 = targets[targets[:, 0] == 0]
+    lab = rpn_match(anchors.to(DEV), only0.to(DEV), 2, H, W).cpu()
+    assert torch.equal(lab[0], want[0]) and torch.all(lab[1] == -2)
+    assert torch.all(rpn_match(anchors.to(DEV), torch.zeros(0, 6, device=DEV), 1, H, W) == -2)
+    pos, neg = rpn_sample(got[0], 128, 128)
+    assert pos.numel() == min(int((want[0] >= 0).sum()), 128) and pos.numel() + neg.numel() == 256
+    assert torch.all(got[0][pos] >= 0) and torch.all(got[0][neg] == -1)

@@ -32,3 +32,49 @@ def test_filter_proposals_matches_reference():
             want = GOLD[f'{c}_prop{b}']
             assert p.shape == want.shape and want.shape[0] <= post
             assert np.array_equal(p.numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------ matcher
+MATCH = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_match.npz'))
+MCASES = sorted({k.split('_')[0] for k in MATCH.files})
+
+
+def check_labels_against_reference(c, labels):
+    """labels [B, Na] int64 vs what the reference's computet_loss revealed (tests/golden/rpn_match.npz): per image the exact
+    sets of negative and positive anchors, and for every positive anchor the regression target of the box it was matched to."""
+    B, H, W, A, T = (int(v) for v in MATCH[f'{c}_shape'])
+    anchors = R.make_anchors_xywh(MATCH[f'{c}_base_wh'], H, W).view(-1, 4)
+    targets = torch.from_numpy(MATCH[f'{c}_targets'])
+    scale = torch.tensor([W, H, W, H], dtype=torch.float32)
+    pos_rows = iter(range(len(MATCH[f'{c}_pos_anchor'])))
+    for b in range(B):
+        sel = MATCH[f'{c}_image'] == b
+        ref_pos = MATCH[f'{c}_anchor'][sel & (MATCH[f'{c}_is_pos'] == 1)]
+        ref_neg = MATCH[f'{c}_anchor'][sel & (MATCH[f'{c}_is_pos'] == 0)]
+        lab = labels[b]
+        assert np.array_equal(torch.nonzero(lab >= 0).flatten().numpy(), ref_pos)           # ascending anchor index, like the reference
+        assert np.array_equal(torch.nonzero(lab == -1).flatten().numpy(), ref_neg)
+        assert int((lab == -2).sum()) == lab.numel() - len(ref_pos) - len(ref_neg)
+        boxes = targets[targets[:, 0] == b][:, 2:] * scale
+        for a in ref_pos:
+            row = next(pos_rows)
+            assert MATCH[f'{c}_pos_anchor'][row] == a
+            want = MATCH[f'{c}_pos_dxdydwdh'][row]
+            got = R.xywh2dxdydwdh(boxes[lab[a]][None], anchors[a][None])[0].numpy()
+            # identifies the matched box; log() differs in the last bit between host CPUs (vectorised libm), so not array_equal
+            assert np.allclose(got, want, rtol=2e-6, atol=1e-6), (c, b, a, int(lab[a]))
+
+
+def test_matcher_labels_match_reference():
+    for c in MCASES:
+        B, H, W, A, T = (int(v) for v in MATCH[f'{c}_shape'])
+        anchors = R.make_anchors_xywh(MATCH[f'{c}_base_wh'], H, W)
+        labels = R.rpn_match(anchors, torch.from_numpy(MATCH[f'{c}_targets']), B, H, W)
+        assert (labels >= 0).sum() > 0 and (labels == -1).sum() > 0
+        check_labels_against_reference(c, labels)
+
+
+def test_sampler_sizes_follow_reference_rule():
+    lab = torch.tensor([-1] * 300 + [0, 1, 2] + [-2] * 50)
+    pos, neg = R.rpn_sample(lab, 128, 128, perm_pos=torch.arange(3), perm_neg=torch.arange(300))
+    assert pos.tolist() == [300, 301, 302] and neg.numel() == 253 and neg[0] == 0          # 128 + 128 - 3 negatives fill the batch
