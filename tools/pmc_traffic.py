@@ -34,17 +34,19 @@ def main():
         wc, wt = w.get(n, [0, 0.0])
         rd, wr = 2 * tot / cnt * 1024 / 1e6, (wt / wc * 1024 / 1e6 if wc else 0.0)
         if rd + wr > 1.0:
-            lines.append(f"| `{re.sub(r'[(].*', '', n)[:70]}` | {cnt} | {rd:.1f} | {wr:.1f} |")
+            nm = re.sub(r'[(].*', '', n.replace('(anonymous namespace)::', ''))[:70]
+            lines.append(f"| `{nm}` | {cnt} | {rd:.1f} | {wr:.1f} |")
     for cls, pred in CLASSES.items():
         names = [n for n in f if pred(n)]
         main_launches = sum(f[n][0] for n in names if 'reduce' not in n)
-        rd = sum(2 * f[n][1] for n in names) * 1024
-        wr = sum(w.get(n, [0, 0.0])[1] for n in names) * 1024
-        out[cls] = {'bytes_per_launch': round((rd + wr) / main_launches), 'read_bytes_per_launch': round(rd / main_launches),
-                    'write_bytes_per_launch': round(wr / main_launches), 'launches_profiled': main_launches,
+        w_launches = sum(w[n][0] for n in names if 'reduce' not in n and n in w) or 1      # the two passes may run a different number of steps
+        rd = sum(2 * f[n][1] for n in names) * 1024 / main_launches
+        wr = sum(w.get(n, [0, 0.0])[1] for n in names) * 1024 / w_launches
+        out[cls] = {'bytes_per_launch': round(rd + wr), 'read_bytes_per_launch': round(rd),
+                    'write_bytes_per_launch': round(wr), 'launches_profiled': main_launches,
                     'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled (gfx950)'}
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
-    open(sys.argv[4], 'w').write('# HBM traffic per launch (PMC), bench.py B=32 640x640 bf16, 3 steps\n\n' + '\n'.join(lines) +
+    open(sys.argv[4], 'w').write('# HBM traffic per launch (PMC), bench.py B=32 640x640 bf16, weight gradients on the launch stream (FVA_WGRAD_STREAM=0)\n\n' + '\n'.join(lines) +
                                  '\n\nPer conv class (all tile variants pooled, per conv call):\n\n```\n' + json.dumps(out, indent=1) + '\n```\n')
     print(json.dumps(out, indent=1))
 
