@@ -72,6 +72,7 @@ extern "C" int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32
 // enqueued on `main` so far; join: `main` waits for everything enqueued on the side stream so far.
 namespace {
 hipStream_t g_side = nullptr;
+int g_side_dev = -1;
 hipEvent_t g_side_ev[64];
 int g_side_next = 0;
 hipEvent_t side_event() { return g_side_ev[g_side_next++ & 63]; }
@@ -79,7 +80,12 @@ hipEvent_t side_event() { return g_side_ev[g_side_next++ & 63]; }
 
 extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
     if (!side_stream) return fva_fail(FVA_ERR_ARG, "fva_side_stream_fork: null pointer");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (g_side && dev != g_side_dev)   // one process per GPU is the model; a second device in the same process stays on its launch stream
+        return fva_fail(FVA_ERR_ARG, "fva_side_stream_fork: the side stream belongs to device %d, current device is %d", g_side_dev, dev);
     if (!g_side) {
+        g_side_dev = dev;
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
             hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess)

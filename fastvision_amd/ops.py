@@ -346,7 +346,11 @@ def wgrad_stream(buffers, weight=None):
     if not _SIDE['on'] or torch.is_grad_enabled() or (weight is not None and weight.grad is not None):
         return _stream()
     side = C.c_void_p()
-    _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
+    try:
+        _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
+    except RuntimeError:                          # e.g. a second device in this process: everything stays on the launch stream
+        _SIDE['on'] = False
+        return _stream()
     _SIDE['keep'].append(buffers)
     # one callback per launch, not one per backward pass: a pass that dies with an exception never runs its callbacks, and a
     # "queued" flag left behind by it would leave the next pass without a join (all but the first callback find nothing to do)
