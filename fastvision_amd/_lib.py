@@ -112,6 +112,7 @@ PROTOTYPES = {
     'fva_nms_select_workspace': (_L, [_I, _I]),
     'fva_rpn_decode': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'fva_rpn_match': (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'fva_fast_match': (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _P]),
     'fva_roi_align_fwd': (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),

@@ -477,9 +477,11 @@ __device__ __forceinline__ float rpn_iou(float ax, float ay, float aw, float ah,
 }
 
 // labels of phase 1: one thread per (image, anchor); the image's boxes are the rows of targets with column 0 == image
+// (the Fast head's variant, fast.py:117-127: positive if best >= pos_thr, negative if neg_floor <= best < neg_thr, no claims)
 __global__ __launch_bounds__(256) void rpn_label_kernel(const float* __restrict__ anchors, int Na, const float* __restrict__ targets, int T,
-                                                        float fw, float fh, float pos_thr, float neg_thr, int32_t* __restrict__ labels) {
-    const int b = blockIdx.y;
+                                                        float fw, float fh, float pos_thr, float neg_thr, int32_t* __restrict__ labels,
+                                                        int image_base, int pos_inclusive, float neg_floor) {
+    const int b = image_base + blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     if (a >= Na) return;
     const float4 an = *(const float4*)(anchors + (int64_t)a * 4);
@@ -494,10 +496,10 @@ __global__ __launch_bounds__(256) void rpn_label_kernel(const float* __restrict_
     }
     int lab = -2;
     if (local > 0) {
-        if (best > pos_thr) lab = best_t;
-        if (best < neg_thr) lab = -1;          // the reference applies this test second: it wins when both hold
+        if (pos_inclusive ? best >= pos_thr : best > pos_thr) lab = best_t;
+        if (best < neg_thr && best >= neg_floor) lab = -1;          // the reference applies this test second: it wins when both hold
     }
-    labels[(int64_t)b * Na + a] = lab;
+    labels[(int64_t)blockIdx.y * Na + a] = lab;
 }
 
 // phase 2: one block per (box row): arg-max of its IoU over the anchors (first maximum), wave shuffles + LDS
@@ -549,7 +551,7 @@ extern "C" int fva_rpn_match(const float* anchors_xywh, int32_t Na, const float*
         return fva_fail(FVA_ERR_ARG, "fva_rpn_match: bad argument");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rpn_label_kernel, dim3(cdiv(Na, 256), B), dim3(256), 0, s, anchors_xywh, Na, targets, T, (float)feature_w, (float)feature_h,
-                       pos_thr, neg_thr, labels);
+                       pos_thr, neg_thr, labels, 0, 0, -INFINITY);
     FVA_LAUNCH_CHECK("rpn_label_kernel");
     if (T > 0) {
         hipLaunchKernelGGL(rpn_best_anchor_kernel, dim3(T), dim3(256), 0, s, anchors_xywh, Na, targets, (float)feature_w, (float)feature_h, workspace);
@@ -557,5 +559,18 @@ extern "C" int fva_rpn_match(const float* anchors_xywh, int32_t Na, const float*
         hipLaunchKernelGGL(rpn_claim_kernel, dim3(B), dim3(64), 0, s, targets, T, workspace, Na, labels);
         FVA_LAUNCH_CHECK("rpn_claim_kernel");
     }
+    return FVA_OK;
+}
+
+// Fast head (demos/faster_rcnn/models/fast.py:100-127): the proposals of ONE image against that image's boxes (targets rows with
+// column 0 == image; their xywh already in feature cells, fast.py:217).  labels [N]: >= 0 matched box (best IoU >= pos_thr),
+// -1 negative (neg_floor <= best IoU < neg_thr), -2 ignored.
+extern "C" int fva_fast_match(const float* proposals_xywh, int32_t N, const float* targets, int32_t T, int32_t image, float pos_thr,
+                              float neg_thr, float neg_floor, int32_t* labels, void* stream) {
+    if (N < 0 || T < 0 || (N > 0 && (!proposals_xywh || !labels)) || (T > 0 && !targets)) return fva_fail(FVA_ERR_ARG, "fva_fast_match: bad argument");
+    if (N == 0) return FVA_OK;
+    hipLaunchKernelGGL(rpn_label_kernel, dim3(cdiv(N, 256), 1), dim3(256), 0, (hipStream_t)stream, proposals_xywh, N, targets, T, 1.f, 1.f, pos_thr,
+                       neg_thr, labels, image, 1, neg_floor);
+    FVA_LAUNCH_CHECK("rpn_label_kernel<fast>");
     return FVA_OK;
 }

@@ -11,7 +11,7 @@ from . import _lib
 from .detect_ops import nms_batch
 from .ops import _p, _stream, require_gpu
 
-__all__ = ['filter_proposals', 'rpn_proposal_rows', 'rpn_match', 'rpn_sample']
+__all__ = ['filter_proposals', 'rpn_proposal_rows', 'rpn_match', 'rpn_sample', 'fast_match', 'fast_select_samples']
 
 _MODE = dict(box_mode=1, score_mode=1, rethreshold=0, class_gap=0.0)
 
@@ -68,3 +68,34 @@ def rpn_sample(labels_image, positives_per_image=128, negatives_per_image=128, p
     perm_pos = torch.randperm(pos.numel(), device=labels_image.device) if perm_pos is None else perm_pos
     perm_neg = torch.randperm(neg.numel(), device=labels_image.device) if perm_neg is None else perm_neg
     return pos[perm_pos[:n_pos]], neg[perm_neg[:n_neg]]
+
+
+def fast_match(proposals_xywh, targets, image, pos_thr=0.5, neg_thr=0.5, neg_floor=0.1):
+    """Labelling of one image's proposals against its boxes (fast.py:113-127) on the device: [N] int64."""
+    require_gpu(proposals_xywh, 'fast_match')
+    prop = proposals_xywh.detach().float().contiguous()
+    tg = targets.detach().to(device=prop.device, dtype=torch.float32).contiguous()
+    N, T = prop.size(0), tg.size(0)
+    labels = torch.empty(N, dtype=torch.int32, device=prop.device)
+    _lib.call('fva_fast_match', _p(prop) if N else None, N, _p(tg) if T else None, T, int(image), float(pos_thr), float(neg_thr),
+              float(neg_floor), _p(labels) if N else None, _stream())
+    return labels.long()
+
+
+def fast_select_samples(proposals, targets, pos_thr=0.5, neg_thr=0.5, positives_per_image=16, negatives_per_image=48, perms=None):
+    """Fast.select_positive_negative_samples (fast.py:100-166): proposals = list over images of [n, 4] xywh (filter_proposals),
+    targets [T, 6] = image, class, xywh in feature cells -> (positives [P, 10], negatives [Q, 5]) like the reference.  The
+    labelling runs in the HIP matcher; gathering the few dozen sampled rows is torch indexing."""
+    dev = proposals[0].device
+    tg = targets.to(device=dev, dtype=torch.float32)
+    all_pos, all_neg = [], []
+    for b, prop in enumerate(proposals):
+        lab = fast_match(prop, tg, b, pos_thr, neg_thr)
+        pos, neg = rpn_sample(lab, positives_per_image, negatives_per_image, *(perms[b] if perms is not None else (None, None)))
+        mine = tg[tg[:, 0] == b]
+        boxes, pp = mine[:, 2:][lab[pos]], prop[pos].float()
+        reg = torch.stack([(boxes[:, 0] - pp[:, 0]) / pp[:, 2], (boxes[:, 1] - pp[:, 1]) / pp[:, 3],
+                           torch.log(boxes[:, 2] / pp[:, 2] + 1e-7), torch.log(boxes[:, 3] / pp[:, 3] + 1e-7)], 1)
+        all_pos.append(torch.cat([torch.full((pos.numel(), 1), float(b), device=dev), pp, reg, mine[:, 1:2][lab[pos]]], 1))
+        all_neg.append(torch.cat([torch.full((neg.numel(), 1), float(b), device=dev), prop[neg].float()], 1))
+    return torch.cat(all_pos, 0), torch.cat(all_neg, 0)

@@ -364,6 +364,13 @@ int fva_rpn_decode(const float* cls, const float* deltas, const float* anchors_w
 int fva_rpn_match(const float* anchors_xywh, int32_t Na, const float* targets, int32_t T, int32_t B, int32_t feature_h,
                   int32_t feature_w, float pos_thr, float neg_thr, int32_t* labels, int32_t* workspace, void* stream);
 
+/* Fast head: proposal / ground-truth labelling of select_positive_negative_samples (demos/faster_rcnn/models/fast.py:100-127)
+ * for ONE image: proposals_xywh [N][4]; targets [T][6] as above but with xywh already in feature cells (fast.py:217), only the
+ * rows of `image` count.  labels [N] i32: >= 0 matched box (best IoU >= pos_thr), -1 negative (neg_floor <= best IoU <
+ * neg_thr; the reference's floor is 0.1), -2 ignored. */
+int fva_fast_match(const float* proposals_xywh, int32_t N, const float* targets, int32_t T, int32_t image, float pos_thr,
+                   float neg_thr, float neg_floor, int32_t* labels, void* stream);
+
 /* ---- RoIAlign (two-stage head) -----------------------------------------------------------------------------
  * torchvision.ops.roi_align as the reference calls it (demos/faster_rcnn/models/fast.py:227-231,258): rois [K][5] = (batch
  * index, x1, y1, x2, y2), out [K][C][PH][PW] fp32 (the order torch.flatten(.., 1) feeds the classifier), aligned = False,

@@ -781,6 +781,38 @@ def gen_rpn_match(RPN, get_base_anchor):
         out[f'm{case}_is_pos'] = tc.long().numpy()
         out[f'm{case}_pos_anchor'] = pb[:, 0].long().numpy()       # positives again, image after image
         out[f'm{case}_pos_dxdydwdh'] = tbx.numpy()                 # xywh2dxdydwdh(matched box, anchor)
+    # Fast head: select_positive_negative_samples RETURNS its samples; with randperm = identity and unbounded sample sizes they
+    # are every positive / negative proposal of every image (fast.py:100-166)
+    from models.fast import Fast
+    for case, (B, n, T, H, W) in enumerate([(2, 300, 9, 38, 50), (3, 80, 14, 14, 14)]):
+        fast = Fast(training=True, module_after_roi=torch.nn.Identity(), in_channels=8, num_classes=20, fast_positives_per_image=10 ** 7,
+                    fast_negatives_per_image=10 ** 7)
+        g = torch.Generator().manual_seed(900 + case)
+        tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
+        twh = torch.exp(np.log(0.08) + (np.log(0.8) - np.log(0.08)) * torch.rand(T, 2, generator=g))
+        txy = twh / 2 + (1 - twh) * torch.rand(T, 2, generator=g)
+        targets = torch.cat([tb[:, None], torch.randint(0, 20, (T, 1), generator=g).float(), txy, twh], 1) * torch.tensor([1, 1, W, H, W, H])
+        proposals = []
+        for b in range(B):
+            mine = targets[targets[:, 0] == b][:, 2:]
+            near = mine[torch.randint(0, mine.size(0), (n // 2,), generator=g)] * (1 + 0.35 * (torch.rand(n // 2, 4, generator=g) - 0.5))
+            wh = torch.exp(np.log(1.0) + (np.log(30.0) - np.log(1.0)) * torch.rand(n - n // 2, 2, generator=g))
+            far = torch.cat([torch.rand(n - n // 2, 2, generator=g) * torch.tensor([W, H]), wh], 1)
+            p = torch.cat([near, far], 0)[torch.randperm(n, generator=g)]
+            if b == 0:
+                p[0] = mine[0]                                   # IoU exactly 1
+            proposals.append(p)
+        real_perm = torch.randperm
+        torch.randperm = lambda k, device=None: torch.arange(k)
+        try:
+            pos, neg = fast.select_positive_negative_samples([p.clone() for p in proposals], targets.clone(), 'cpu')
+        finally:
+            torch.randperm = real_perm
+        out[f'f{case}_shape'] = np.array([B, n, T, H, W])
+        out[f'f{case}_targets'] = targets.numpy()
+        for b in range(B):
+            out[f'f{case}_prop{b}'] = proposals[b].numpy()
+        out[f'f{case}_pos'], out[f'f{case}_neg'] = pos.numpy(), neg.numpy()
     np.savez_compressed(os.path.join(GOLD, 'rpn_match.npz'), **out)
     print('rpn match fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_match.npz')), 'bytes')
 

@@ -110,3 +110,33 @@ def xywh2dxdydwdh(target_xywh, anchor_xywh, eps=1e-7):
     """rpn.py:123-131: regression targets of matched (box, anchor) pairs"""
     return torch.stack([(target_xywh[:, 0] - anchor_xywh[:, 0]) / anchor_xywh[:, 2], (target_xywh[:, 1] - anchor_xywh[:, 1]) / anchor_xywh[:, 3],
                         torch.log(target_xywh[:, 2] / anchor_xywh[:, 2] + eps), torch.log(target_xywh[:, 3] / anchor_xywh[:, 3] + eps)], 1)
+
+
+# ------------------------------------------------------------------------------------------------ Fast head samples (fast.py:100-166)
+def fast_match(proposals_xywh, image_boxes_xywh, pos_thr=0.5, neg_thr=0.5, neg_floor=0.1):
+    """fast.py:113-127 for one image: [N] int64 -- >= 0 matched box (best IoU >= pos_thr), -1 negative (neg_floor <= best <
+    neg_thr), -2 ignored"""
+    lab = torch.full((proposals_xywh.size(0),), -2, dtype=torch.int64)
+    if proposals_xywh.size(0) == 0 or image_boxes_xywh.size(0) == 0:
+        return lab
+    best, idx = torch.max(batch_iou(proposals_xywh, image_boxes_xywh), dim=1)
+    m = best >= pos_thr
+    lab[m] = idx[m]
+    lab[(best < neg_thr) & (best >= neg_floor)] = -1
+    return lab
+
+
+def fast_select_samples(proposals, targets, pos_thr=0.5, neg_thr=0.5, positives_per_image=16, negatives_per_image=48, perms=None):
+    """select_positive_negative_samples (fast.py:100-166): proposals = list over images of [n, 4] xywh, targets [T, 6] with xywh in
+    feature cells -> (positives [P, 10] = image, proposal xywh, regression target, class; negatives [Q, 5] = image, proposal
+    xywh).  perms: per image (perm_pos, perm_neg) instead of torch.randperm."""
+    all_pos, all_neg = [], []
+    for b, prop in enumerate(proposals):
+        tg = targets[targets[:, 0] == b]
+        lab = fast_match(prop, tg[:, 2:], pos_thr, neg_thr)
+        pos, neg = rpn_sample(lab, positives_per_image, negatives_per_image, *(perms[b] if perms is not None else (None, None)))
+        boxes = tg[:, 2:][lab[pos]]
+        all_pos.append(torch.cat([torch.full((pos.numel(), 1), float(b)), prop[pos], xywh2dxdydwdh(boxes, prop[pos]).view(-1, 4),
+                                  tg[:, 1:2][lab[pos]]], 1))
+        all_neg.append(torch.cat([torch.full((neg.numel(), 1), float(b)), prop[neg]], 1))
+    return torch.cat(all_pos, 0), torch.cat(all_neg, 0)

@@ -102,3 +102,26 @@ def test_matcher_full_size_equals_oracle_and_edge_cases():
     pos, neg = rpn_sample(got[0], 128, 128)
     assert pos.numel() == min(int((want[0] >= 0).sum()), 128) and pos.numel() + neg.numel() == 256
     assert torch.all(got[0][pos] >= 0) and torch.all(got[0][neg] == -1)
+
+
+# ------------------------------------------------------------------------------------------------ Fast head samples
+from tests.test_oracle_rpn_golden import FCASES, check_fast_samples, fast_case  # noqa: E402
+
+
+@pytest.mark.parametrize('c', FCASES)
+def test_fast_samples_equal_reference(c):
+    from fastvision_amd.rpn_ops import fast_match, fast_select_samples
+    from oracle import rpn as R
+    proposals, targets, B = fast_case(c)
+    for b, p in enumerate(proposals):                          # index work: the labels themselves, bit-exact with the restatement
+        want = R.fast_match(p, targets[targets[:, 0] == b][:, 2:])
+        assert torch.equal(fast_match(p.to(DEV), targets.to(DEV), b).cpu(), want)
+    perms = [(torch.arange(p.size(0), device=DEV), torch.arange(p.size(0), device=DEV)) for p in proposals]
+    pos, neg = fast_select_samples([p.to(DEV) for p in proposals], targets.to(DEV), 0.5, 0.5, 10 ** 7, 10 ** 7, perms=perms)
+    check_fast_samples(c, pos.cpu().numpy(), neg.cpu().numpy())
+    # the reference's sample sizes (16 + 48 per image): 64 rows per image in total when there are enough candidates
+    pos2, neg2 = fast_select_samples([p.to(DEV) for p in proposals], targets.to(DEV))
+    for b in range(B):
+        nb = int((pos2[:, 0] == b).sum()) + int((neg2[:, 0] == b).sum())
+        assert nb <= 64 and int((pos2[:, 0] == b).sum()) <= 16
+    assert fast_match(torch.zeros(0, 4, device=DEV), targets.to(DEV), 0).numel() == 0

@@ -36,7 +36,7 @@ def test_filter_proposals_matches_reference():
 
 # ------------------------------------------------------------------------------------------------ matcher
 MATCH = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_match.npz'))
-MCASES = sorted({k.split('_')[0] for k in MATCH.files})
+MCASES = sorted({k.split('_')[0] for k in MATCH.files if k.startswith('m')})
 
 
 def check_labels_against_reference(c, labels):
@@ -78,3 +78,32 @@ def test_sampler_sizes_follow_reference_rule():
     lab = torch.tensor([-1] * 300 + [0, 1, 2] + [-2] * 50)
     pos, neg = R.rpn_sample(lab, 128, 128, perm_pos=torch.arange(3), perm_neg=torch.arange(300))
     assert pos.tolist() == [300, 301, 302] and neg.numel() == 253 and neg[0] == 0          # 128 + 128 - 3 negatives fill the batch
+
+
+# ------------------------------------------------------------------------------------------------ Fast head samples
+FCASES = sorted({k.split('_')[0] for k in MATCH.files if k.startswith('f')})
+
+
+def fast_case(c):
+    B, n, T, H, W = (int(v) for v in MATCH[f'{c}_shape'])
+    return [torch.from_numpy(MATCH[f'{c}_prop{b}']) for b in range(B)], torch.from_numpy(MATCH[f'{c}_targets']), B
+
+
+def check_fast_samples(c, pos, neg):
+    """(positives [P,10], negatives [Q,5]) vs the reference's select_positive_negative_samples with randperm = identity and
+    unbounded sample sizes: same rows in the same order; the regression targets go through log() (last-bit differences
+    between CPUs), everything else is copied data and must be equal."""
+    want_pos, want_neg = MATCH[f'{c}_pos'], MATCH[f'{c}_neg']
+    assert pos.shape == want_pos.shape and neg.shape == want_neg.shape and len(want_pos) > 0 and len(want_neg) > 0
+    assert np.array_equal(neg, want_neg)
+    assert np.array_equal(pos[:, :5], want_pos[:, :5]) and np.array_equal(pos[:, 9], want_pos[:, 9])
+    assert np.allclose(pos[:, 5:9], want_pos[:, 5:9], rtol=2e-6, atol=1e-6)
+
+
+def test_fast_samples_match_reference():
+    for c in FCASES:
+        proposals, targets, B = fast_case(c)
+        big = 10 ** 7
+        perms = [(torch.arange(p.size(0)), torch.arange(p.size(0))) for p in proposals]
+        pos, neg = R.fast_select_samples(proposals, targets, 0.5, 0.5, big, big, perms=perms)
+        check_fast_samples(c, pos.numpy(), neg.numpy())
