@@ -6,9 +6,9 @@
 // roi_align_kernel (see oracle/roi_align.py), in fp32.
 //
 // Layout: the feature map is this library's halo NHWC tensor [B][H+2p][W+2p][C] (fp32 or bf16): the four taps of a sample
-// are four contiguous channel vectors, so a wave reads whole lines -- one block per (box, 64-channel slice), lane = channel.
+// are four contiguous channel vectors, so a wave reads whole lines -- one block per (box, 64-channel slice, output row), lane = channel.
 // The result leaves in the reference's [K][C][PH][PW] order (what torch.flatten(.., 1) feeds the classifier): the block's
-// [64][PH*PW] tile is contiguous there and is written from an LDS transpose.  HBM/L2-bound gather; latency-bound for the
+// [64][PW] rows are written from an LDS transpose (PW floats per channel and row of bins).  HBM/L2-bound gather; latency-bound for the
 // K <= a few thousand boxes of one step.
 // Backward: the same walk scatters grad / count * weight into a dense fp32 NHWC gradient with float atomics (channel-
 // contiguous, so a wave's atomics hit consecutive addresses); the sum order is not fixed -- fp32 rounding differences only.
@@ -71,10 +71,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
     const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
     const int nbins = p.PH * p.PW;
     const bool live = c < p.C;
-    for (int bin0 = 0; bin0 < nbins; bin0 += 49) {
-        const int nb = min(49, nbins - bin0);
+    const int ph = blockIdx.z;                                            // one output row of bins per block
+    for (int pw0 = 0; pw0 < p.PW; pw0 += 49) {
+        const int nb = min(49, p.PW - pw0);
         for (int bi = sub; bi < nb; bi += 4) {
-            const int bin = bin0 + bi, ph = bin / p.PW, pw = bin - ph * p.PW;
+            const int pw = pw0 + bi, bin = ph * p.PW + pw;
             if constexpr (!BWD) {
                 float acc = 0.f;
                 if (live) {
@@ -103,12 +104,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
         }
         if constexpr (!BWD) {
             __syncthreads();
-            // out[((k*C + c) * nbins + bin]: the slice c0 .. c0+63 is one contiguous run of 64 * nbins floats
-            float* o = p.out + ((int64_t)k * p.C + c0) * nbins;
+            // out[(k*C + c) * nbins + ph*PW + pw]: per channel a run of nb floats
+            float* o = p.out + ((int64_t)k * p.C + c0) * nbins + ph * p.PW + pw0;
             const int cmax = min(RC, p.C - c0);
             for (int e = threadIdx.x; e < cmax * nb; e += 256) {
                 const int cc = e / nb, bi = e - cc * nb;
-                o[(int64_t)cc * nbins + bin0 + bi] = tile[cc][bi];
+                o[(int64_t)cc * nbins + bi] = tile[cc][bi];
             }
             __syncthreads();
         }
@@ -119,7 +120,7 @@ int check(const char* who, int dtype, const void* feat, const float* rois, const
     if (dtype != FVA_F32 && dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "%s: bad dtype", who);
     if (K < 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || PH <= 0 || PW <= 0) return fva_fail(FVA_ERR_ARG, "%s: bad shape", who);
     if (K > 0 && (!feat || !rois || !io)) return fva_fail(FVA_ERR_ARG, "%s: null pointer", who);
-    if (K > 65535 * 1024) return fva_fail(FVA_ERR_ARG, "%s: too many boxes", who);
+    if (K > 65535 * 1024 || PH > 65535) return fva_fail(FVA_ERR_ARG, "%s: too many boxes / bins", who);
     return FVA_OK;
 }
 
@@ -134,7 +135,7 @@ int fva_roi_align_fwd(int dtype, const void* feat, int feat_pad, const float* ro
     RoiParams p{};
     p.feat = feat; p.rois = rois; p.out = out; p.B = B; p.H = H; p.W = W; p.C = C; p.pad = feat_pad; p.K = K; p.PH = PH; p.PW = PW;
     p.scale = spatial_scale; p.sampling = sampling_ratio;
-    const dim3 grid(K, cdiv(C, RC));
+    const dim3 grid(K, cdiv(C, RC), PH);
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL((roi_align_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
@@ -150,7 +151,7 @@ int fva_roi_align_bwd(const float* grad_out, const float* rois, int K, float* df
     RoiParams p{};
     p.rois = rois; p.out = const_cast<float*>(grad_out); p.dfeat = dfeat; p.B = B; p.H = H; p.W = W; p.C = C; p.pad = 0; p.K = K;
     p.PH = PH; p.PW = PW; p.scale = spatial_scale; p.sampling = sampling_ratio;
-    hipLaunchKernelGGL((roi_align_kernel<float, true>), dim3(K, cdiv(C, RC)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((roi_align_kernel<float, true>), dim3(K, cdiv(C, RC), PH), dim3(256), 0, (hipStream_t)stream, p);
     FVA_LAUNCH_CHECK("roi_align_kernel<bwd>");
     return FVA_OK;
 }
