@@ -25,7 +25,8 @@ struct IgemmParams {
     void* out;
     float* stats;
     const float* bias;
-    const float* scale;  // EPI_BNACT: per-output-channel affine (eval-mode BatchNorm folded in) before SiLU
+    const float* scale;  // EPI_BNACT: per-output-channel affine (eval-mode BatchNorm folded in) before SiLU; NULL = 1 (bias only)
+    int act;             // EPI_BNACT: 0 SiLU, 1 ReLU (VGG blocks of the two-stage head), 2 none
     const float* shift;
     int M, N, C;
     int OW, OHW;
@@ -41,6 +42,11 @@ struct IgemmParams {
     const void* addend;  // optional tensor added in the epilogue (same addressing as out)
     int nblocks;         // column blocks
 };
+
+__device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
+    const float u = (p.scale ? v * p.scale[n] : v) + p.shift[n];
+    return p.act == 0 ? silu_f(u) : p.act == 1 ? fmaxf(u, 0.f) : u;
+}
 
 template <typename T>
 struct Acc;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     pix_cache = out_pixel(m);
                 }
                 const int64_t oi = pix_cache * p.out_pitch + n;
-                if constexpr (EPI == EPI_BNACT) v = silu_f(v * p.scale[n] + p.shift[n]);
+                if constexpr (EPI == EPI_BNACT) v = bnact_f(p, v, n);
                 out[oi] = p.addend ? ((const float*)p.addend)[oi] + v : v;
             }
         });
@@ -353,7 +359,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         foreach_acc(acc, lane, [&](int row, int col, int, float v) {
             if constexpr (EPI == EPI_BNACT) {
                 const int n = n0 + wcol0 + col < p.N ? n0 + wcol0 + col : p.N - 1;
-                v = silu_f(v * p.scale[n] + p.shift[n]);
+                v = bnact_f(p, v, n);
             }
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         // bf16 tile through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
         foreach([&](int row, int col, int, float v) {
-            if constexpr (EPI == EPI_BNACT) v = silu_f(v * p.scale[n0 + col] + p.shift[n0 + col]);
+            if constexpr (EPI == EPI_BNACT) v = bnact_f(p, v, n0 + col);
             *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
         });
         __syncthreads();
@@ -1159,6 +1165,32 @@ int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd,
     p.scale = scale;
     p.shift = shift;
     p.addend = residual;          // same halo geometry as z
+    p.out_dense = 0;
+    p.out_row = OW + 2 * z_pad;
+    p.out_img = (OH + 2 * z_pad) * p.out_row;
+    p.osy = p.osx = 1;
+    p.ooy = p.oox = z_pad;
+    FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    rc = launch_igemm<EPI_BNACT>(d->dtype, p, (hipStream_t)stream);
+    if (rc || z_pad == 0) return rc;
+    return fva_zero_halo_border(z, d->B, OH, OW, d->Cout * (d->dtype == FVA_BF16 ? 2 : 4) / 16, z_pad, (hipStream_t)stream);
+}
+
+int fva_conv_fwd_bias_act(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, int32_t act, void* z, int32_t z_pad,
+                          void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_conv_fwd_bias_act");
+    if (rc) return rc;
+    if (!x || !w_fwd || !bias || !z) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bias_act: null pointer");
+    if (d->Cout % 8 || z_pad < 0 || act < 1 || act > 2) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bias_act: Cout %d not a multiple of 8, bad z_pad or act", d->Cout);
+    const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
+    p.in = x;
+    p.wt = w_fwd;
+    p.out = z;
+    p.scale = nullptr;
+    p.shift = bias;
+    p.act = act;
+    p.addend = nullptr;
     p.out_dense = 0;
     p.out_row = OW + 2 * z_pad;
     p.out_img = (OH + 2 * z_pad) * p.out_row;

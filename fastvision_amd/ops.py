@@ -343,8 +343,8 @@ def wgrad_stream(buffers, weight=None):
     """Stream argument for a weight-gradient launch (called from inside a backward pass).  A parameter that already holds a
     gradient (accumulation over micro-batches) gets its dW added by autograd on the main stream right after this backward
     returns, so that layer stays on the main stream; so does everything under create_graph."""
-    if not _SIDE['on'] or torch.is_grad_enabled() or (weight is not None and weight.grad is not None):
-        return _stream()
+    if not _SIDE['on'] or torch.is_grad_enabled() or (weight is not None and (not weight.is_leaf or weight.grad is not None)):
+        return _stream()          # (a derived weight, e.g. a channel-padded filter: autograd's next node reads dW on the main stream)
     side = C.c_void_p()
     try:
         _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
