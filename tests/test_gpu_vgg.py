@@ -106,3 +106,49 @@ def test_bias_relu_backward_kernel_exact_fp32():
     assert torch.equal(dy[:, 1:-1, 1:-1], want)
     assert (dy[:, 0] == 0).all() and (dy[:, -1] == 0).all() and (dy[:, :, 0] == 0).all() and (dy[:, :, -1] == 0).all()
     assert torch.allclose(db, want.sum((0, 1, 2)), rtol=1e-5, atol=1e-5)
+
+
+def test_vgg16_backbone_keys_numerics_and_timing():
+    """The demo's backbone (fastvision_amd.demos.faster_rcnn.models.vgg16): reference state_dict keys, fp32 forward/backward vs a
+    plain torch stack with the same weights at a small size, and the bf16 forward+backward time at the reference's training shape."""
+    import time
+    import fastvision_amd
+    from fastvision_amd.demos.faster_rcnn.models import vgg16
+    torch.manual_seed(0)
+    net = vgg16().to(DEV)
+    convs = [f'vgg{s}.{2 * i}' for s, n in zip(range(1, 6), (2, 2, 3, 3, 3)) for i in range(n)]
+    want_keys = [f'{c}.{p}' for c in convs for p in ('weight', 'bias')] + [f'classifier.{i}.{p}' for i in (0, 3) for p in ('weight', 'bias')]
+    assert list(net.state_dict().keys()) == want_keys
+    feats = [m for n, m in net.named_modules() if isinstance(m, nn.Conv2d)]
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(1))
+
+    def torch_stack(t):
+        k = 0
+        for stage, n in enumerate((2, 2, 3, 3, 3)):
+            for _ in range(n):
+                t = F.relu(F.conv2d(t, feats[k].weight.detach().cpu(), feats[k].bias.detach().cpu(), 1, 1))
+                k += 1
+            if stage < 4:
+                t = F.max_pool2d(t, 2, 2)
+        return t
+    want = torch_stack(x)
+    with fastvision_amd.compute_dtype(torch.float32):
+        got = net(x.to(DEV))
+        assert tuple(got.shape) == (2, 512, 4, 6)
+        assert rel(got.float().cpu(), want) < 2e-4
+        got.square().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in net.named_parameters() if n.startswith('vgg'))
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        xb = torch.randn(4, 3, 608, 800, device=DEV)
+        for i in range(4):
+            if i == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            net.zero_grad(set_to_none=True)
+            out = net(xb)
+            out.float().square().mean().backward()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    assert tuple(out.shape) == (4, 512, 38, 50)
+    flop = 2 * 3 * 4 * sum(m.weight.numel() * hw for m, hw in zip(feats, [608 * 800] * 2 + [304 * 400] * 2 + [152 * 200] * 3 + [76 * 100] * 3 + [38 * 50] * 3))
+    print(f'VGG16 backbone 4x3x608x800 bf16 forward+backward: {ms:.1f} ms ({flop / ms / 1e9:.0f} TFLOP/s of conv work, fwd + dgrad + wgrad)')
