@@ -727,6 +727,54 @@ def gen_rpn():
     print('rpn fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_proposals.npz')), 'bytes')
 
 
+def gen_rpn_step(RPN, get_base_anchor):
+    """One training forward + backward of the reference's RPN module on a random feature map: weights, inputs, the permutations
+    torch.randperm produced (recorded, so that the path under test can use the same draws), the two losses and gradient
+    statistics of every parameter and of the feature map."""
+    import torch
+    out = {}
+    B, C, H, W, T = 2, 64, 12, 16, 7
+    torch.manual_seed(77)
+    base = torch.from_numpy(get_base_anchor(scales=[64, 128, 256], ratios=[0.5, 1, 2]))
+    rpn = RPN(training=True, base_anchors=base, backbone_stride=16, in_channels=C, rpn_positives_per_image=16, rpn_negatives_per_image=48)
+    g = torch.Generator().manual_seed(78)
+    for p in rpn.parameters():                                 # livelier than the std = 0.01 init: losses that depend on every path
+        p.data = torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.1)
+    feature = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
+    wh = torch.exp(np.log(0.15) + (np.log(0.7) - np.log(0.15)) * torch.rand(T, 2, generator=g))
+    xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+    targets = torch.cat([tb[:, None], torch.zeros(T, 1), xy, wh], 1)
+    perms, real_perm = [], torch.randperm
+    pg = torch.Generator().manual_seed(79)
+
+    def recorded(n, device=None):
+        p = real_perm(n, generator=pg)
+        perms.append(p.clone())
+        return p
+    torch.randperm = recorded
+    try:
+        proposals, loss_cls, loss_box = rpn(feature, targets)
+    finally:
+        torch.randperm = real_perm
+    (loss_cls + loss_box).backward()
+    out['shape'] = np.array([B, C, H, W, T])
+    out['base_anchors_px'] = base.numpy()
+    for k, v in rpn.state_dict().items():
+        out['w_' + k] = v.numpy()
+    out['feature'], out['targets'] = feature.detach().numpy(), targets.numpy()
+    for i, p in enumerate(perms):
+        out[f'perm{i}'] = p.numpy()
+    out['loss_cls'], out['loss_box'] = loss_cls.detach().numpy(), loss_box.detach().numpy()
+    out['grad_feature'] = feature.grad.numpy()
+    for k, p in rpn.named_parameters():
+        out['g_' + k] = p.grad.numpy()
+    for b, p in enumerate(proposals):
+        out[f'prop{b}'] = p.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, 'rpn_step.npz'), **out)
+    print('rpn step fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_step.npz')), 'bytes; losses', float(loss_cls), float(loss_box))
+
+
 def gen_rpn_match(RPN, get_base_anchor):
     """The labelling inside RPN.computet_loss is not returned by anything, so the reference is made to reveal it: the class
     logits fed to it carry (anchor index, image index) instead of scores, the regression carries the anchor index, torch.randperm
@@ -814,6 +862,7 @@ def gen_rpn_match(RPN, get_base_anchor):
             out[f'f{case}_prop{b}'] = proposals[b].numpy()
         out[f'f{case}_pos'], out[f'f{case}_neg'] = pos.numpy(), neg.numpy()
     np.savez_compressed(os.path.join(GOLD, 'rpn_match.npz'), **out)
+    gen_rpn_step(RPN, get_base_anchor)
     print('rpn match fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_match.npz')), 'bytes')
 
 

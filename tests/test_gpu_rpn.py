@@ -125,3 +125,35 @@ def test_fast_samples_equal_reference(c):
         nb = int((pos2[:, 0] == b).sum()) + int((neg2[:, 0] == b).sum())
         assert nb <= 64 and int((pos2[:, 0] == b).sum()) <= 16
     assert fast_match(torch.zeros(0, 4, device=DEV), targets.to(DEV), 0).numel() == 0
+
+
+# ------------------------------------------------------------------------------------------------ the whole RPN module, one training step
+def test_rpn_module_training_step_vs_reference():
+    """fastvision_amd.demos.faster_rcnn.models.RPN (conv3x3 + ReLU, the two 1x1 heads, proposals, matcher, sampler, focal and
+    smooth-L1 losses, backward through the heads and the conv) against one forward + backward of the reference's RPN class on the
+    same weights, inputs and randperm draws (tests/golden/rpn_step.npz), fp32."""
+    import fastvision_amd
+    from fastvision_amd.demos.faster_rcnn.models import RPN
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_step.npz'))
+    B, C, H, W, T = (int(v) for v in G['shape'])
+    rpn = RPN(training=True, base_anchors=torch.from_numpy(G['base_anchors_px']), backbone_stride=16, in_channels=C,
+              rpn_positives_per_image=16, rpn_negatives_per_image=48).to(DEV)
+    rpn.load_state_dict({k[2:]: torch.from_numpy(G[k]) for k in G.files if k.startswith('w_')})
+    feature = torch.from_numpy(G['feature']).to(DEV).requires_grad_(True)
+    targets = torch.from_numpy(G['targets']).to(DEV)
+    perms = [(torch.from_numpy(G[f'perm{2 * b}']).to(DEV), torch.from_numpy(G[f'perm{2 * b + 1}']).to(DEV)) for b in range(B)]
+    with fastvision_amd.compute_dtype(torch.float32):
+        proposals, loss_cls, loss_box = rpn(feature, targets, perms=perms)
+        (loss_cls + loss_box).backward()
+    np.testing.assert_allclose(loss_cls.item(), G['loss_cls'], rtol=1e-4)
+    np.testing.assert_allclose(loss_box.item(), G['loss_box'], rtol=1e-4)
+    for b, p in enumerate(proposals):
+        assert p.shape == G[f'prop{b}'].shape
+        assert np.allclose(p.detach().cpu().numpy(), G[f'prop{b}'], rtol=1e-4, atol=1e-3)
+
+    def close(got, want, what):
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-12))
+        assert err < 1e-3, (what, err)
+    close(feature.grad.cpu().numpy(), G['grad_feature'], 'feature')
+    for k, p in rpn.named_parameters():
+        close(p.grad.cpu().numpy(), G['g_' + k], k)
