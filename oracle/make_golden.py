@@ -11,7 +11,7 @@ integer ``clamp_`` bound).  No reference source is copied: the fixtures are inpu
                                           # top-level ``utils``/``models`` names clash with nothing else then
     python oracle/make_golden.py eval_lib / eval_demo   # validation side (decode, NMS wrappers, mAP): scope row f-2
     python oracle/make_golden.py pipeline / pipeline_demo   # input side (resize, pad, flips, normalise, labels): row f-3
-    python oracle/make_golden.py rpn      # two-stage head, RPN proposal layer: row f-4
+    python oracle/make_golden.py rpn / faster   # two-stage head (RPN ops and module; the whole Faster R-CNN step): row f-4
     python oracle/make_golden.py all      # everything, one child process per surface
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
@@ -866,6 +866,74 @@ def gen_rpn_match(RPN, get_base_anchor):
     print('rpn match fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'rpn_match.npz')), 'bytes')
 
 
+def gen_faster():
+    """One training forward + backward of the reference's whole Faster_Rcnn model (VGG16 + RPN + Fast head) on the CPU.  Weights are
+    NOT stored (the VGG classifier alone is 103 M values): the model is built right after torch.manual_seed(SEED), so the mirror,
+    which creates the same modules in the same order, starts from the same values -- per-parameter checksums are stored to prove
+    it.  torchvision is absent: nms = the oracle's stand-in, roi_align = oracle.roi_align wrapped as an autograd function;
+    Dropout is set to p = 0 (its masks are not part of the path); torch.randperm draws are recorded."""
+    import torch
+    _stub_missing()
+    _install_nms()
+    from oracle import roi_align as RA
+
+    class RoiAlignStandIn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, boxes, ph, pw):
+            ctx.boxes, ctx.shape = boxes.detach().numpy().copy(), tuple(feat.shape)
+            return torch.from_numpy(RA.roi_align(feat.detach().numpy(), ctx.boxes, (ph, pw)))
+
+        @staticmethod
+        def backward(ctx, g):
+            return torch.from_numpy(RA.roi_align_backward(g.numpy(), ctx.boxes, ctx.shape)), None, None, None
+    sys.modules['torchvision.ops'].roi_align = lambda feat, boxes, output_size: RoiAlignStandIn.apply(feat, boxes, output_size[0], output_size[1])
+    sys.path.insert(0, os.path.join(REF, 'demos', 'faster_rcnn'))
+    from models.faster import Faster_Rcnn
+    from utils.anchor_generator import get_base_anchor
+    SEED, B, H, W, T, NC = 4321, 2, 96, 128, 6, 20
+    base = torch.from_numpy(get_base_anchor(scales=[32, 64, 128], ratios=[0.5, 1, 2]))
+    torch.manual_seed(SEED)
+    model = Faster_Rcnn(training=True, num_classes=NC, base_anchors=base, rpn_positives_per_image=16, rpn_negatives_per_image=48,
+                        fast_positives_per_image=8, fast_negatives_per_image=24)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    g = torch.Generator().manual_seed(SEED + 1)
+    images = torch.rand(B, 3, H, W, generator=g)
+    tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
+    wh = torch.exp(np.log(0.2) + (np.log(0.7) - np.log(0.2)) * torch.rand(T, 2, generator=g))
+    xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+    targets = torch.cat([tb[:, None], torch.randint(0, NC, (T, 1), generator=g).float(), xy, wh], 1)
+    perms, real_perm = [], torch.randperm
+    pg = torch.Generator().manual_seed(SEED + 2)
+
+    def recorded(n, device=None):
+        p = real_perm(n, generator=pg)
+        perms.append(p.clone())
+        return p
+    torch.randperm = recorded
+    try:
+        proposals, l_rc, l_rb, l_fc, l_fb = model(images, targets.clone())
+    finally:
+        torch.randperm = real_perm
+    (l_rc + l_rb + l_fc + l_fb).backward()
+    out = {'meta': np.array([SEED, B, H, W, T, NC]), 'base_anchors_px': base.numpy(), 'images': images.numpy(), 'targets': targets.numpy(),
+           'losses': np.array([float(l_rc), float(l_rb), float(l_fc), float(l_fb)])}
+    for i, p in enumerate(perms):
+        out[f'perm{i}'] = p.numpy()
+    names = []
+    for k, p in model.named_parameters():
+        names.append(k)
+        out['wsum_' + k] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+        gr = p.grad.double()
+        out['gstat_' + k] = np.array([gr.sum().item(), gr.abs().sum().item(), gr.norm().item()] + gr.flatten()[:3].tolist())
+    out['param_names'] = np.array(names)
+    for b, p in enumerate(proposals):
+        out[f'nprop{b}'] = np.array([p.size(0)])
+    np.savez_compressed(os.path.join(GOLD, 'faster_step.npz'), **out)
+    print('faster fixtures:', len(out), 'arrays', os.path.getsize(os.path.join(GOLD, 'faster_step.npz')), 'bytes; losses', out['losses'], 'perms', [len(p) for p in perms])
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLD, exist_ok=True)
@@ -883,7 +951,9 @@ if __name__ == '__main__':
         gen_pipeline_demo()
     elif which == 'rpn':
         gen_rpn()
+    elif which == 'faster':
+        gen_faster()
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for s in ('lib', 'demo', 'eval_lib', 'eval_demo', 'pipeline', 'pipeline_demo', 'rpn'):
+        for s in ('lib', 'demo', 'eval_lib', 'eval_demo', 'pipeline', 'pipeline_demo', 'rpn', 'faster'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s], env=env)

@@ -1,0 +1,65 @@
+"""The reference's Faster R-CNN demo model on the HIP ops (scope row f-4): one training forward + backward of
+fastvision_amd.demos.faster_rcnn.models.Faster_Rcnn against the reference's own model on the CPU (tests/golden/faster_step.npz,
+oracle/make_golden.py faster): same seeded initialisation (proved by per-parameter checksums), same images, boxes and randperm
+draws; the four losses and the gradient of every parameter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'faster_step.npz'))
+
+
+def build():
+    from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
+    seed, B, H, W, T, NC = (int(v) for v in G['meta'])
+    torch.manual_seed(seed)
+    model = Faster_Rcnn(training=True, num_classes=NC, base_anchors=torch.from_numpy(G['base_anchors_px']), rpn_positives_per_image=16,
+                        rpn_negatives_per_image=48, fast_positives_per_image=8, fast_negatives_per_image=24)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model, B
+
+
+def test_same_seed_gives_the_reference_initialisation():
+    model, _ = build()
+    names = [k for k, _ in model.named_parameters()]
+    assert names == list(G['param_names'])
+    for k, p in model.named_parameters():
+        want = G['wsum_' + k]
+        got = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9), k
+
+
+def test_training_step_losses_and_gradients_vs_reference():
+    import fastvision_amd
+    model, B = build()
+    model = model.to(DEV)
+    images = torch.from_numpy(G['images']).to(DEV)
+    targets = torch.from_numpy(G['targets']).to(DEV)
+    perms = [(torch.from_numpy(G[f'perm{2 * i}']).to(DEV), torch.from_numpy(G[f'perm{2 * i + 1}']).to(DEV)) for i in range(2 * B)]
+    with fastvision_amd.compute_dtype(torch.float32):
+        proposals, l_rc, l_rb, l_fc, l_fb = model(images, targets.clone(), perms=perms)
+        (l_rc + l_rb + l_fc + l_fb).backward()
+    got = np.array([float(l_rc), float(l_rb), float(l_fc), float(l_fb)])
+    print('losses', got, 'reference', G['losses'])
+    np.testing.assert_allclose(got, G['losses'], rtol=2e-3)
+    for b, p in enumerate(proposals):
+        assert abs(p.size(0) - int(G[f'nprop{b}'][0])) <= 2          # a near-tie in NMS may keep one box more or less
+    worst = 0.0
+    for k, p in model.named_parameters():
+        want = G['gstat_' + k]
+        gr = p.grad.double()
+        norm = gr.norm().item()
+        err = abs(norm - want[2]) / max(want[2], 1e-12)
+        head = (gr.flatten()[:3].cpu().numpy() - want[3:6])
+        worst = max(worst, err)
+        assert err < 5e-3, (k, norm, want[2])
+        # single entries of the deepest layers' gradients (1e-8 .. 1e-7 here, sums over every pixel of every path) carry fp32
+        # summation-order noise of a few percent of the tensor's largest entry; the norm above is the tight check
+        assert np.abs(head).max() <= 3e-2 * max(gr.abs().max().item(), 1e-12) + 1e-9, (k, head)
+    print('largest relative gradient-norm deviation', worst)
