@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Faster R-CNN (the reference's demo model: VGG16 stride-16 backbone + RPN + Fast head) training step on the HIP ops, at
+BASELINE config 5's input: 4 x 3 x 800 x 1333 synthetic images, 20 classes, the demo's defaults (128 + 128 RPN samples,
+16 + 48 Fast samples per image), bf16 compute, SGD like demos/faster_rcnn/train.py.  Prints one JSON object.
+usage: python tools/bench_faster.py [steps]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import fastvision_amd
+from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
+
+DEV = 'cuda:0'
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    B, H, W, NC = 4, 800, 1333, 20
+    torch.manual_seed(0)
+    scales, ratios = [128, 256, 512], [0.5, 1, 2]
+    base = torch.tensor([[(s * s / r) ** 0.5, s * s / (s * s / r) ** 0.5] for r in ratios for s in scales], dtype=torch.float32)
+    model = Faster_Rcnn(training=True, num_classes=NC, base_anchors=base).to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    T = 28
+    tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
+    wh = torch.exp(np.log(0.08) + (np.log(0.6) - np.log(0.08)) * torch.rand(T, 2, generator=g))
+    xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+    targets = torch.cat([tb[:, None], torch.randint(0, NC, (T, 1), generator=g).float(), xy, wh], 1).to(DEV)
+
+    def step():
+        _, a, b, c, d = model(images, targets.clone())
+        opt.zero_grad()
+        loss = a + b + c + d
+        loss.backward()
+        opt.step()
+        return loss
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        for _ in range(3):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    print(json.dumps({'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, SGD, synthetic',
+                      'ms_per_step': round(ms, 2), 'images_per_sec': round(B / (ms * 1e-3), 2), 'steps': steps, 'loss': round(float(loss), 4),
+                      'note': 'conv / pool / RoIAlign / matchers / proposal layer on the HIP kernels, FC layers rocBLAS via torch, '
+                              'losses and sampling torch ops; host-inclusive (each step reads sample counts back like the reference)'}))
+
+
+if __name__ == '__main__':
+    main()
