@@ -252,3 +252,38 @@ def test_config1_resnet18_cpu_fit_plumbing(tmp_path, monkeypatch):
     assert len(losses) == 4 and all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]                                             # the same batch four times: it must fit it
     assert (tmp_path / 'last.pth').exists()
+
+
+def test_faster_rcnn_fit_loop_contract(tmp_path, monkeypatch):
+    """demos/faster_rcnn/cfg/_fit.py mirror: four losses summed, backward, global-norm clipping at 10, step; lr / 10 at every
+    ninth epoch; a state_dict checkpoint per epoch (reference _fit.py:6-50)."""
+    import types
+    import torch
+    from fastvision_amd.demos.faster_rcnn.cfg import _fit
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([3.0, 4.0]))
+
+        def forward(self, images, targets):
+            l = (self.w * images).sum()
+            return None, l * 100, l * 0, l * 0, targets.sum() * self.w.sum() * 0
+    net = Net()
+    net.w.grad = torch.tensor([30.0, 40.0])
+    assert abs(_fit.clip_gradient(net, 10.) - 50.0) < 1e-4 and torch.allclose(net.w.grad, torch.tensor([6.0, 8.0]))
+    net.w.grad = torch.tensor([0.3, 0.4])
+    _fit.clip_gradient(net, 10.)
+    assert torch.allclose(net.w.grad, torch.tensor([0.3, 0.4]))                      # below the bound: untouched
+    opt = torch.optim.SGD(net.parameters(), lr=1.0)
+    logged = []
+    _fit._Train(net, [(torch.ones(2), torch.zeros(1))], opt, log=lambda *v: logged.append(v))
+    assert torch.allclose(net.w.detach(), torch.tensor([3.0, 4.0]) - 10 * torch.tensor([1.0, 1.0]) / 2 ** 0.5, atol=1e-5)   # gradient (100, 100) clipped to norm 10
+    assert len(logged) == 1 and len(logged[0]) == 5 and abs(logged[0][0] - 700.0) < 1e-3
+    args = types.SimpleNamespace(start_epoch=7, total_epoch=9)
+    _fit.Fit(net, args, opt, [(torch.ones(2), torch.zeros(1))])
+    assert abs(opt.param_groups[0]['lr'] - 0.1) < 1e-12                               # epoch 9: divided by ten
+    assert (tmp_path / '8.pth').exists() and (tmp_path / '9.pth').exists()
+    assert set(torch.load(tmp_path / '9.pth')) == {'w'}
