@@ -63,3 +63,23 @@ def test_training_step_losses_and_gradients_vs_reference():
         # summation-order noise of a few percent of the tensor's largest entry; the norm above is the tight check
         assert np.abs(head).max() <= 3e-2 * max(gr.abs().max().item(), 1e-12) + 1e-9, (k, head)
     print('largest relative gradient-norm deviation', worst)
+
+
+def test_inference_forward_shapes_and_ranges():
+    """training=False: backbone -> RPN proposals -> Fast head -> per image [n, 6] = xywh (feature cells), class, score;
+    background rows dropped (fast.py:248-286)."""
+    import fastvision_amd
+    from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
+    seed, B, H, W, T, NC = (int(v) for v in G['meta'])
+    torch.manual_seed(seed)
+    model = Faster_Rcnn(training=False, num_classes=NC, base_anchors=torch.from_numpy(G['base_anchors_px']), rpn_post_nms_top_n=100).to(DEV).eval()
+    images = torch.from_numpy(G['images']).to(DEV)
+    with torch.no_grad(), fastvision_amd.compute_dtype(torch.float32):
+        preds = model(images)
+    assert len(preds) == B
+    for p in preds:
+        assert p.dim() == 2 and p.size(1) == 6 and p.size(0) <= 100
+        if p.size(0):
+            assert torch.isfinite(p).all()
+            assert p[:, 4].min() >= 0 and p[:, 4].max() <= NC - 1 and torch.all(p[:, 4] == p[:, 4].round())
+            assert p[:, 5].min() > 0 and p[:, 5].max() <= 1
