@@ -113,7 +113,8 @@ PROTOTYPES = {
     'fva_conv_fwd_bias_act': (_I, [_D, _P, _P, _P, _I, _P, _I, _P]),
     'fva_bias_relu_bwd_rows': (_I, [_I, _I, _I]),
     'fva_bias_relu_bwd': (_I, [_I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
-    'fva_colsum': (_I, [_P, _I, _I, _P, _P]),
+    'fva_colsum_scratch_rows': (_I, [_I]),
+    'fva_colsum': (_I, [_P, _I, _I, _P, _P, _P]),
     'fva_maxpool2_fwd': (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'fva_maxpool2_bwd': (_I, [_I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     'fva_rpn_decode': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -123,7 +124,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_bias_relu_bwd_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

@@ -56,15 +56,18 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const T* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
+// column sums of rows [r0, r1) of part[rows][C], one block per (64 channels, row group); fixed order inside a block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int rows_per_block) {
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     double t = 0.0;
     if (c < C)
-        for (int r = g; r < rows; r += 4) t += (double)part[(int64_t)r * C + c];
+        for (int r = r0 + g; r < r1; r += 4) t += (double)part[(int64_t)r * C + c];
     red[g][threadIdx.x & 63] = t;
     __syncthreads();
-    if (g == 0 && c < C) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (g == 0 && c < C)
+        out[(int64_t)blockIdx.y * C + c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // one block per padded output row
@@ -164,9 +167,19 @@ int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void*
     return FVA_OK;
 }
 
-int fva_colsum(const float* partial, int32_t rows, int C, float* out, void* stream) {
+int32_t fva_colsum_scratch_rows(int32_t rows) { return rows > 256 ? cdiv(rows, 64) : 0; }
+
+int fva_colsum(const float* partial, int32_t rows, int C, float* out, float* scratch, void* stream) {
     if (!partial || !out || rows <= 0 || C <= 0) return fva_fail(FVA_ERR_ARG, "fva_colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, rows, C, out);
+    hipStream_t s = (hipStream_t)stream;
+    const int groups = fva_colsum_scratch_rows(rows);
+    if (groups > 0 && scratch) {           // two passes: 64 rows per block, then the group sums (a single block per 64 channels otherwise)
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), groups), dim3(256), 0, s, partial, rows, C, scratch, 64);
+        FVA_LAUNCH_CHECK("colsum_kernel");
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1), dim3(256), 0, s, scratch, groups, C, out, groups);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1), dim3(256), 0, s, partial, rows, C, out, rows);
+    }
     FVA_LAUNCH_CHECK("colsum_kernel");
     return FVA_OK;
 }

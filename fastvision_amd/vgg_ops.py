@@ -49,7 +49,9 @@ class ConvBiasReLUFn(torch.autograd.Function):
         part = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bias_relu_bwd', code, C.c_void_p(dz_ptr), _p(zbuf), 1, _p(dy), 1, _p(part), B, H, W, Cout, _stream())
         dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
-        _lib.call('fva_colsum', _p(part), rows, Cout, _p(dbias), _stream())
+        srows = lib.fva_colsum_scratch_rows(rows)
+        scratch = torch.empty((srows, Cout), dtype=torch.float32, device=dev) if srows else None
+        _lib.call('fva_colsum', _p(part), rows, Cout, _p(dbias), _p(scratch) if srows else None, _stream())
         dw = torch.empty(wshape, dtype=torch.float32, device=dev)
         wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

@@ -353,7 +353,7 @@ int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int6
  * fva_conv_fwd_bias_act: z = act(conv(x) + bias[n]) straight into the halo buffer z (border zeroed), act 1 = ReLU, 2 = none;
  *   its backward uses fva_conv_dgrad / fva_conv_wgrad on dY from
  * fva_bias_relu_bwd: dY = dZ * (Z > 0) (dZ dense NHWC, Z the forward's halo output) into the halo buffer dY, and partial
- *   [fva_bias_relu_bwd_rows()][C] column sums of dY that fva_colsum adds up in fixed order (= dbias).
+ *   [fva_bias_relu_bwd_rows()][C] column sums of dY that fva_colsum adds up in fixed order (= dbias; scratch may be NULL).
  * fva_maxpool2_fwd: 2x2 / stride 2 max of the halo tensor x [B][H+2p][W+2p][C] into the halo tensor out [B][H/2+2q][W/2+2q][C]
  *   (floor mode; border zeroed).  fva_maxpool2_bwd: dz dense [B][H/2][W/2][C] -> dx dense [B][H][W][C]; the gradient goes to the
  *   first maximum of each window in scan order. */
@@ -362,7 +362,8 @@ int fva_conv_fwd_bias_act(const fva_conv_desc* d, const void* x, const void* w_f
 int32_t fva_bias_relu_bwd_rows(int B, int H, int dy_pad);
 int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void* dy, int dy_pad, float* partial, int B, int H, int W, int C,
                       void* stream);
-int fva_colsum(const float* partial, int32_t rows, int C, float* out, void* stream);
+int32_t fva_colsum_scratch_rows(int32_t rows);   /* rows of [C] floats fva_colsum wants as scratch for its two-pass form (0: none) */
+int fva_colsum(const float* partial, int32_t rows, int C, float* out, float* scratch, void* stream);
 int fva_maxpool2_fwd(int dtype, const void* x, int x_pad, void* out, int out_pad, int B, int H, int W, int C, void* stream);
 int fva_maxpool2_bwd(int dtype, const void* dz, const void* x, int x_pad, void* dx, int B, int H, int W, int C, void* stream);
 

@@ -101,7 +101,12 @@ def test_bias_relu_backward_kernel_exact_fp32():
     part = torch.empty(rows, Cc, device=DEV)
     _lib.call('fva_bias_relu_bwd', 0, ops._p(dz), ops._p(z), 1, ops._p(dy), 1, ops._p(part), B, H, W, Cc, ops._stream())
     db = torch.empty(Cc, device=DEV)
-    _lib.call('fva_colsum', ops._p(part), rows, Cc, ops._p(db), ops._stream())
+    _lib.call('fva_colsum', ops._p(part), rows, Cc, ops._p(db), None, ops._stream())
+    big = torch.randn(1000, Cc, device=DEV)                       # the two-pass form
+    scratch = torch.empty(lib.fva_colsum_scratch_rows(1000), Cc, device=DEV)
+    db2 = torch.empty(Cc, device=DEV)
+    _lib.call('fva_colsum', ops._p(big), 1000, Cc, ops._p(db2), ops._p(scratch), ops._stream())
+    assert torch.allclose(db2, big.double().sum(0).float(), rtol=1e-5, atol=1e-4)
     want = dz * (z[:, 1:-1, 1:-1] > 0)
     assert torch.equal(dy[:, 1:-1, 1:-1], want)
     assert (dy[:, 0] == 0).all() and (dy[:, -1] == 0).all() and (dy[:, :, 0] == 0).all() and (dy[:, :, -1] == 0).all()
