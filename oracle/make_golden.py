@@ -898,6 +898,12 @@ def gen_faster():
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+    # the default initialisation shrinks activations by ~0.6x per layer (1e-3 after 13 layers: the heads would see zeros and the
+    # losses would not depend on the backbone): scale the backbone's filters so that the feature map stays O(1)
+    CONV_SCALE = 1.7
+    for m in model.backbone.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data *= CONV_SCALE
     g = torch.Generator().manual_seed(SEED + 1)
     images = torch.rand(B, 3, H, W, generator=g)
     tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
@@ -917,7 +923,7 @@ def gen_faster():
     finally:
         torch.randperm = real_perm
     (l_rc + l_rb + l_fc + l_fb).backward()
-    out = {'meta': np.array([SEED, B, H, W, T, NC]), 'base_anchors_px': base.numpy(), 'images': images.numpy(), 'targets': targets.numpy(),
+    out = {'meta': np.array([SEED, B, H, W, T, NC]), 'conv_scale': np.array([CONV_SCALE]), 'base_anchors_px': base.numpy(), 'images': images.numpy(), 'targets': targets.numpy(),
            'losses': np.array([float(l_rc), float(l_rb), float(l_fc), float(l_fb)])}
     for i, p in enumerate(perms):
         out[f'perm{i}'] = p.numpy()

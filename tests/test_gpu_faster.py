@@ -22,6 +22,9 @@ def build():
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+    for m in model.backbone.modules():               # same filter scaling as the golden run (keeps the feature map O(1))
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data *= float(G['conv_scale'][0])
     return model, B
 
 
