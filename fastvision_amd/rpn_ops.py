@@ -33,8 +33,15 @@ def filter_proposals(cls, dxdydwdh, base_anchors_wh, pre_nms_top_n=2000, post_nm
     """-> list over images of [n, 4] xywh in feature-map cells, best score first (rpn.py:186-209)."""
     rows = rpn_proposal_rows(cls, dxdydwdh, base_anchors_wh)
     R = rows.size(1)
-    # every row is a candidate (scores are probabilities > -1); the max_nms best enter NMS, max_det survive
-    dets = nms_batch(rows, -1.0, nms_thresh, min(post_nms_top_n, R), dict(_MODE, max_nms=min(pre_nms_top_n, R)))
+    k = min(pre_nms_top_n, R)
+    # Only the k best rows of an image enter NMS.  The candidate stage ranks what it is given against each other (quadratic), so
+    # it is handed a score floor just below the smallest per-image k-th best score: every image keeps at least its k best rows
+    # (ties included), ~k instead of all R = h*w*A rows get ranked.  (-1 = no floor when k == R.)
+    floor = -1.0
+    if k < R:
+        kth = rows[..., 4].topk(k, dim=1).values[:, -1].min()
+        floor = float(torch.nextafter(kth, kth.new_tensor(-1.0)))
+    dets = nms_batch(rows, floor, nms_thresh, min(post_nms_top_n, R), dict(_MODE, max_nms=k))
     out = []
     for det, _ in dets:
         xyxy = det[:, :4]
