@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Faster R-CNN (the reference's demo model: VGG16 stride-16 backbone + RPN + Fast head) training step on the HIP ops, at
 BASELINE config 5's input: 4 x 3 x 800 x 1333 synthetic images, 20 classes, the demo's defaults (128 + 128 RPN samples,
-16 + 48 Fast samples per image), bf16 compute, SGD like demos/faster_rcnn/train.py.  Prints one JSON object.
+16 + 48 Fast samples per image), bf16 compute, the demo's step: SGD (momentum 0.937, Nesterov) after gradient-norm clipping at 10.  Prints one JSON object.
 usage: python tools/bench_faster.py [steps]"""
 import json
 import os
@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 import fastvision_amd
+from fastvision_amd.demos.faster_rcnn.cfg._fit import clip_gradient
 from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
 
 DEV = 'cuda:0'
@@ -25,7 +26,7 @@ def main():
     scales, ratios = [128, 256, 512], [0.5, 1, 2]
     base = torch.tensor([[(s * s / r) ** 0.5, s * s / (s * s / r) ** 0.5] for r in ratios for s in scales], dtype=torch.float32)
     model = Faster_Rcnn(training=True, num_classes=NC, base_anchors=base).to(DEV)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.937, nesterov=True)      # demos/faster_rcnn/train.py:102
     g = torch.Generator().manual_seed(1)
     images = torch.rand(B, 3, H, W, generator=g).to(DEV)
     T = 28
@@ -39,6 +40,7 @@ def main():
         opt.zero_grad()
         loss = a + b + c + d
         loss.backward()
+        clip_gradient(model, 10.)                  # part of the reference's step (cfg/_fit.py:46); one read-back
         opt.step()
         return loss
     with fastvision_amd.compute_dtype(torch.bfloat16):
@@ -50,7 +52,7 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, SGD, synthetic',
+    print(json.dumps({'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
                       'ms_per_step': round(ms, 2), 'images_per_sec': round(B / (ms * 1e-3), 2), 'steps': steps, 'loss': round(float(loss), 4),
                       'note': 'conv / pool / RoIAlign / matchers / proposal layer on the HIP kernels, FC layers rocBLAS via torch, '
                               'losses and sampling torch ops; host-inclusive (each step reads sample counts back like the reference)'}))
