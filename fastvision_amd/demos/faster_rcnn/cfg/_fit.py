@@ -16,7 +16,7 @@ def clip_gradient(model, clip_norm):
     grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
     if not grads:
         return 0.0
-    total = torch.sqrt(torch.stack([g.detach().float().norm() ** 2 for g in grads]).sum()).item()
+    total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)).float()).item()     # sqrt(sum of squared norms), one read-back
     scale = clip_norm / max(total, clip_norm)
     if scale != 1.0:
         torch._foreach_mul_(grads, scale)

@@ -93,8 +93,14 @@ def conv_bias_relu(x, conv, dtype=None):
     weight, cin = conv.weight, conv.weight.shape[1]
     if cin % _CIN_ALIGN:                     # the RGB input of the first block: zero channels (and zero filter taps) up to 32
         extra = _CIN_ALIGN - cin % _CIN_ALIGN
-        x = F.pad(x, (0, 0, 0, 0, 0, extra))
         weight = F.pad(weight, (0, 0, 0, 0, 0, extra))
+        if x.requires_grad:
+            x = F.pad(x, (0, 0, 0, 0, 0, extra))
+        else:                                # an image batch: written straight into a zeroed halo buffer, no padded fp32 copy
+            B, _, H, W = x.shape
+            buf = torch.zeros((B, H + 2, W + 2, cin + extra), dtype=dtype, device=x.device)
+            buf[:, 1:-1, 1:-1, :cin] = x.permute(0, 2, 3, 1)
+            x = buf[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
     return ConvBiasReLUFn.apply(x, weight, conv.bias, dtype)
 
 
