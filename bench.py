@@ -197,28 +197,11 @@ def main():
         if len(st):
             wall_us = (st[:, 2] - st[:, 1]).double() / 100.0
             clock_mhz = float(((st[:, 6] - st[:, 5]).double() / wall_us).median())
-    # The side stream is the product default, but whether the two HIP streams really share the GPU is up to the queue
-    # arbitration of the box (one run in a few, right after other GPU processes had exited, took 57 ms per step with it and
-    # the usual 33 ms without): time three steps each way and keep the faster setting.  Collective: every rank must agree.
-    def window(n=3):
-        fence()
-        t = time.perf_counter()
-        for _ in range(n):
-            step()
-        fence()
-        w = (time.perf_counter() - t) / n
-        if world > 1:
-            tw = torch.tensor([w], device=dev, dtype=torch.float64)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            w = tw.item()
-        return w * 1e3
-    side_check = {'off': round(window(), 3)}
-    side_use = side_was
-    if side_was:
-        fva_ops.set_wgrad_side_stream(True)
-        step()
-        side_check['on'] = round(window(), 3)
-        side_use = side_check['on'] <= side_check['off']
+    # The side stream is the product default, but whether two HIP streams share the GPU to advantage depends on the box and on
+    # the collective backend: the library times three steps each way and keeps the faster setting (collectively).
+    fva_ops.set_wgrad_side_stream(side_was)
+    side_check = fva_ops.autotune_wgrad_side_stream(step, fence, steps=3)
+    side_use = side_check.pop('use')
     fva_ops.set_wgrad_side_stream(side_use)
     step()
     fence()
