@@ -106,3 +106,56 @@ def test_training_step_bf16_close_to_reference():
     # the sampled sets can differ from the fp32 run's (bf16 scores reorder near-tied proposals), so the Fast losses get more room
     np.testing.assert_allclose(got[:2], G['losses'][:2], rtol=5e-2)
     np.testing.assert_allclose(got[2:], G['losses'][2:], rtol=2.5e-1)
+
+
+def test_training_step_vs_cpu_oracle_other_seed_and_size():
+    """Away from the golden case: another seed, image size and box set -- the HIP model against the CPU restatement
+    (oracle/faster.py, itself pinned by the reference's vectors), sharing the oracle's randperm draws."""
+    import copy
+    import fastvision_amd
+    from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
+    from oracle import faster as OF
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    B, H, W, T, NC = 2, 112, 144, 5, 7
+    torch.manual_seed(99)
+    base = torch.tensor([[45.3, 22.6], [90.5, 45.3], [32, 32], [64, 64], [22.6, 45.3], [45.3, 90.5]])
+    model = Faster_Rcnn(training=True, num_classes=NC, base_anchors=base, rpn_positives_per_image=12, rpn_negatives_per_image=20,
+                        fast_positives_per_image=6, fast_negatives_per_image=10, fast_multi_reg_head=True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    for m in model.backbone.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data *= 1.7
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(B, 3, H, W, generator=g)
+    tb = torch.sort(torch.cat([torch.arange(B), torch.randint(0, B, (T - B,), generator=g)]))[0].float()
+    wh = torch.exp(np.log(0.25) + (np.log(0.7) - np.log(0.25)) * torch.rand(T, 2, generator=g))
+    xy = wh / 2 + (1 - wh) * torch.rand(T, 2, generator=g)
+    targets = torch.cat([tb[:, None], torch.randint(0, NC, (T, 1), generator=g).float(), xy, wh], 1)
+    ref = copy.deepcopy(model)
+    drawn, real = [], torch.randperm
+    pg = torch.Generator().manual_seed(6)
+
+    def recorded(n, device=None):
+        p = real(n, generator=pg)
+        drawn.append(p.clone())
+        return p
+    torch.randperm = recorded
+    try:
+        want = OF.training_losses(ref, images, targets, [(None, None)] * (2 * B))
+    finally:
+        torch.randperm = real
+    torch.stack([l.reshape(()) for l in want[1:]]).sum().backward()
+    perms = [(drawn[2 * i].to(DEV), drawn[2 * i + 1].to(DEV)) for i in range(2 * B)]
+    model = model.to(DEV)
+    with fastvision_amd.compute_dtype(torch.float32):
+        got = model(images.to(DEV), targets.to(DEV).clone(), perms=perms)
+        torch.stack([l.reshape(()) for l in got[1:]]).sum().backward()
+    a = np.array([float(l) for l in got[1:]])
+    b = np.array([float(l) for l in want[1:]])
+    print('losses', a, 'oracle', b)
+    np.testing.assert_allclose(a, b, rtol=1e-4)
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        n1, n2 = p.grad.double().norm().item(), q.grad.double().norm().item()
+        assert abs(n1 - n2) <= 2e-3 * max(n2, 1e-12), (k, n1, n2)

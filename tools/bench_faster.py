@@ -52,7 +52,32 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
+    # CPU baseline: the oracle (oracle/faster.py: plain torch fp32 ops over the same parameters) on a bounded sample -- one image of
+    # the same size per step, on this host's cores
+    import copy
+    from oracle import faster as OF
+    cores = len(os.sched_getaffinity(0))                      # scheduler affinity capped by the cgroup CPU quota (containers)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    ref = copy.deepcopy(model).cpu().float()
+    img1, tg1 = images[:1].cpu(), targets[targets[:, 0] == 0].cpu()
+    cpu_times = []
+    for i in range(2):
+        t0 = time.perf_counter()
+        for p in ref.parameters():
+            p.grad = None
+        out = OF.training_losses(ref, img1, tg1, [(None, None)] * 2)
+        torch.stack([l.reshape(()) for l in out[1:]]).sum().backward()
+        cpu_times.append(time.perf_counter() - t0)
+    cpu = {'value': round(1.0 / cpu_times[-1], 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+           'sample': f'CPU oracle (oracle/faster.py, fp32), forward + backward of 1x3x{H}x{W}: 1 warm-up + 1 timed step, {cpu_times[-1]:.2f} s'}
+    print(json.dumps({'cpu_baseline': cpu, 'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
                       'ms_per_step': round(ms, 2), 'images_per_sec': round(B / (ms * 1e-3), 2), 'steps': steps, 'loss': round(float(loss), 4),
                       'note': 'conv / pool / RoIAlign / matchers / proposal layer on the HIP kernels, FC layers rocBLAS via torch, '
                               'losses and sampling torch ops; host-inclusive (each step reads sample counts back like the reference)'}))
