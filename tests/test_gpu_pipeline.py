@@ -152,3 +152,31 @@ def test_full_size_batch_against_oracle():
     ms = e0.elapsed_time(e1) / 10
     nbytes = src.numel() + images.numel() * 4
     print(f'\npaste_kernel B=32 640x640: {ms * 1e3:.0f} us per batch, {nbytes / ms / 1e6:.0f} GB/s (source bytes once + fp32 batch written)')
+
+
+def test_faster_rcnn_batch_matches_oracle_pipeline():
+    """demos/faster_rcnn/data_gen.py: ResizeByMax -> HorizontalFlip (per sample) -> Padding(128) -> / 255, against the CPU
+    restatement of those steps (oracle/pipeline.py: the classes of the two demos' data_gen.py are the same code)."""
+    from fastvision_amd.demos.faster_rcnn.data_gen import DeviceAugmenter
+    from fastvision_amd.demos.yolov3_u.utils.box import xyxy2xywhn
+    from oracle import pipeline as P
+    rng = np.random.default_rng(3)
+    S = 160
+    samples, want_img, want_lab = [], [], []
+    for i, (h, w) in enumerate([(97, 140), (200, 120), (160, 160), (33, 310)]):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        x1, y1 = rng.uniform(0, w * 0.6, 3), rng.uniform(0, h * 0.6, 3)
+        xyxy = np.stack([x1, y1, x1 + rng.uniform(2, w * 0.4, 3), y1 + rng.uniform(2, h * 0.4, 3)], 1).astype(np.float32)
+        cat = rng.integers(0, 20, 3).astype(np.float32)
+        hflip = bool(i % 2)
+        samples.append((rgb, xyxy, cat, hflip))
+        img, lab = P.demo_resize_by_max(rgb, xyxy.copy(), S)
+        if hflip:
+            img, lab = P.demo_hflip(img, lab)
+        img, lab = P.demo_padding(img, lab.astype(np.float32), S, 128)
+        want_img.append(img.transpose(2, 0, 1).astype(np.float32) / 255.)
+        want_lab.append(np.concatenate([np.full((3, 1), i, np.float32), cat[:, None], xyxy2xywhn(lab, S, S).astype(np.float32)], 1))
+    images, labels = DeviceAugmenter(S, device=DEV).batch(samples)
+    assert tuple(images.shape) == (4, 3, S, S) and tuple(labels.shape) == (12, 6)
+    np.testing.assert_allclose(images.cpu().numpy(), np.stack(want_img), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(labels.cpu().numpy(), np.concatenate(want_lab), rtol=1e-6, atol=1e-6)
