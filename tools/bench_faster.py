@@ -52,6 +52,27 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+    # exclusive per-class convolution figures (HIP events inside the library, weight gradients on the launch stream for this probe)
+    from fastvision_amd import ops as fva_ops
+    from fastvision_amd.profiler import KernelTimer
+    was = fva_ops.set_wgrad_side_stream(False)
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        step()
+        torch.cuda.synchronize()
+        with KernelTimer(pool=4096) as kt:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+    fva_ops.set_wgrad_side_stream(was)
+    summ = kt.summary()
+    dom = max(summ, key=lambda k: summ[k]['ms_total'])
+    peak = 2500.0
+    roofline = {'bound': 'mfma', 'kernel': {'conv_fwd': 'implicit-GEMM convolution forward (igemm8_kernel / igemm_kernel, bias + ReLU epilogue)',
+                                              'conv_dgrad': 'implicit-GEMM convolution dgrad', 'conv_wgrad': 'weight gradient (wgrad8_kernel / wgrad_kernel + reduce)'}[dom],
+                'achieved': round(summ[dom]['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(summ[dom]['tflops'] / peak, 4), 'traffic': None,
+                'avg_launch_ms': round(summ[dom]['ms_avg'], 4), 'launches_per_step': summ[dom]['launches'] // 3,
+                'note': 'dominant convolution class by summed launch time; exclusive timings of a 3-step probe with every kernel on one stream'}
+    kernels = {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / 3, 3), 'launches_per_step': v['launches'] // 3} for k, v in summ.items()}
     # CPU baseline: the oracle (oracle/faster.py: plain torch fp32 ops over the same parameters) on a bounded sample -- one image of
     # the same size per step, on this host's cores
     import copy
@@ -77,7 +98,7 @@ def main():
         cpu_times.append(time.perf_counter() - t0)
     cpu = {'value': round(1.0 / cpu_times[-1], 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
            'sample': f'CPU oracle (oracle/faster.py, fp32), forward + backward of 1x3x{H}x{W}: 1 warm-up + 1 timed step, {cpu_times[-1]:.2f} s'}
-    print(json.dumps({'cpu_baseline': cpu, 'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
+    print(json.dumps({'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
                       'ms_per_step': round(ms, 2), 'images_per_sec': round(B / (ms * 1e-3), 2), 'steps': steps, 'loss': round(float(loss), 4),
                       'note': 'conv / pool / RoIAlign / matchers / proposal layer on the HIP kernels, FC layers rocBLAS via torch, '
                               'losses and sampling torch ops; host-inclusive (each step reads sample counts back like the reference)'}))
