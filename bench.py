@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: YOLOv3 (Darknet-53 + FPN + 3-scale head) train step, 640x640, 32 images per GPU.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+ONE command for N devices, like the reference's nn.DataParallel wrapper (demos/yolov3_u/train.py:85): with N > 1 and no
+torchrun environment, this process -- before it makes any GPU call -- starts `python -m torch.distributed.run` with N ranks of
+itself (one process per GPU, RCCL), relays rank 0's JSON line and exits with the children's status.  Started by
+torch.distributed.run directly (RANK / WORLD_SIZE set) it is simply one of the ranks.
 
 A step = forward + target assignment + yolov3_loss + backward + gradient all-reduce (N > 1) + Adam on one synthetic
 batch that is resident in HBM before the timed region.  Rank 0 prints ONE JSON line: BASELINE.json's metric
@@ -68,6 +73,79 @@ def cpu_baseline(size, budget_s=25.0):
                       f'{batch}x3x{size}x{size}, median {med:.2f} s/step, torch threads = {cores}'}
 
 
+def spawn_ranks(n):
+    """Re-launch this script as ``n`` ranks under torch.distributed.run.  Runs in a parent that has not touched the GPU
+    (importing torch does not initialise HIP; nothing here asks for a device).  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] starting {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode            # the ranks inherit stdout: rank 0 prints the one JSON line
+
+
+def dry_run(args):
+    """No GPU: the launcher, the rendezvous, the bucketed gradient reduction (gloo) and the JSON contract, with the model's
+    real parameter set on the CPU and stand-in gradients -- what a container without a device can check of the N > 1 path.
+    ``value`` is null: nothing of the hot path is measured."""
+    import torch.distributed as dist
+    from fastvision_amd import parallel
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.synthetic import coco_anchors_px
+    rank, world, _ = parallel.init_from_env('gloo')
+    torch.manual_seed(20220504 + rank)
+    net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+                 in_channels=3, num_classes=80, training=True)
+    parallel.broadcast_parameters(net)
+    params = [p for p in net.parameters() if p.requires_grad]
+    reducer = parallel.GradientReducer(params, average=False, bucket_dtype=torch.bfloat16) if world > 1 else None
+
+    def step():
+        for p in params:
+            p.grad = None
+        sum((p * float(rank + 1)).sum() for p in params).backward()      # d/dp = rank + 1 everywhere
+        if reducer is not None:
+            reducer.finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    want = float(world * (world + 1) // 2)                               # SUM over ranks of (rank + 1)
+    ok = all(bool((p.grad == want).all()) for p in params[::17])
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'dry-run (no GPU, gloo, stand-in gradients)',
+                          'dry_run': True, 'reduced_gradients_ok': ok, 'n_params': sum(p.numel() for p in params),
+                          'config': {'workload': 'launcher / rendezvous / gradient-bucket all-reduce only', 'parallelism': f'dp{world}'}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -79,7 +157,12 @@ def main():
     ap.add_argument('--surface', default='lib', choices=['lib', 'demo'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='also print per-layer-shape conv timings to stderr')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU: launcher + rendezvous + gradient reduction over gloo only')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     import torch.distributed as dist
     import fastvision_amd
@@ -88,10 +171,7 @@ def main():
     from fastvision_amd.synthetic import coco_anchors_feature, coco_anchors_px, synthetic_batch
 
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32

@@ -41,7 +41,56 @@ struct IgemmParams {
     int out_img, out_row, osy, osx, ooy, oox, out_pitch;
     const void* addend;  // optional tensor added in the epilogue (same addressing as out)
     int nblocks;         // column blocks
+    // EPI_PLAIN, optional: BatchNorm-backward statistics of the layer that PRODUCED this convolution's input, taken in the dgrad
+    // epilogue that writes dz (= this launch's output incl. the addend, as stored): per block and channel sum(dU) and
+    // sum(dU * xhat), dU = dz * SiLU'(y * scale + shift), xhat = (y - mean) * rstd, with y that layer's pre-BN output (same
+    // [pixel][channel] addressing as the output).  One plain store per block, channel and sum: deterministic.
+    // Table row of block (mblk, column n) = (bnb_row0 + mblk) * (N / bnb_C) + n / bnb_C, column n % bnb_C.
+    const void* bnb_y;
+    const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_rstd;
+    float* bnb_part;
+    int bnb_row0, bnb_C;
 };
+
+// coefficients of eight (bf16 chunk) consecutive channels for the fused BatchNorm-backward statistics
+struct BnbCoef {
+    float sc[8], sh[8], mu[8], rs[8];
+};
+__device__ __forceinline__ void bnb_load(const IgemmParams& p, int n, BnbCoef& k) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int c = n + e;
+        c = c < p.N ? c : p.N - 1;
+        c = c >= p.bnb_C ? c - p.bnb_C : c;      // paired stride-2 dgrad: the columns are two pixels' channels
+        k.sc[e] = p.bnb_scale[c]; k.sh[e] = p.bnb_shift[c]; k.mu[e] = p.bnb_mean[c]; k.rs[e] = p.bnb_rstd[c];
+    }
+}
+// the block's partial sums, gathered per 16-byte column chunk by the threads of the store loop: red[which][group][BN] in LDS ->
+// one store per column and sum
+template <int BN, int NT, int CPR>
+__device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, const float (&s1)[8], const float (&s2)[8], int tid, int mblk,
+                                           int n0) {
+    constexpr int G = NT / CPR;
+    const int cc = tid % CPR, grp = tid / CPR;
+    __syncthreads();   // every thread is done reading the transposed tile
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[(0 * G + grp) * BN + cc * 8 + e] = s1[e];
+        red[(1 * G + grp) * BN + cc * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
+        const int which = i / BN, col = i - which * BN;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) t += red[(which * G + g) * BN + col];
+        const int n = n0 + col;
+        if (n < p.N) {
+            const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
+            p.bnb_part[(((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)] = t;
+        }
+    }
+}
 
 __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
     const float u = (p.scale ? v * p.scale[n] : v) + p.shift[n];
@@ -341,7 +390,18 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         float* out = (float*)p.out;
         int64_t pix_cache = -1;
         int m_cache = -1;
-        foreach_acc(acc, lane, [&](int row, int col, int, float v) {
+        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
+        float b1[2] = {0.f, 0.f}, b2[2] = {0.f, 0.f}, ksc[2], ksh[2], kmu[2], krs[2];
+        if (bnb) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                int c = n0 + wcol0 + nt * 32 + (lane & 31);
+                c = c < p.N ? c : p.N - 1;
+                c = c >= p.bnb_C ? c - p.bnb_C : c;
+                ksc[nt] = p.bnb_scale[c]; ksh[nt] = p.bnb_shift[c]; kmu[nt] = p.bnb_mean[c]; krs[nt] = p.bnb_rstd[c];
+            }
+        }
+        foreach_acc(acc, lane, [&](int row, int col, int nt, float v) {
             const int m = m0 + wrow0 + row, n = n0 + wcol0 + col;
             if (m < p.M && n < p.N) {
                 if (m != m_cache) {
@@ -350,9 +410,46 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 }
                 const int64_t oi = pix_cache * p.out_pitch + n;
                 if constexpr (EPI == EPI_BNACT) v = bnact_f(p, v, n);
-                out[oi] = p.addend ? ((const float*)p.addend)[oi] + v : v;
+                const float o = p.addend ? ((const float*)p.addend)[oi] + v : v;
+                out[oi] = o;
+                if constexpr (EPI == EPI_PLAIN) {
+                    if (bnb) {
+                        const float yv = ((const float*)p.bnb_y)[oi];
+                        const float du = o * silu_grad(yv * ksc[nt] + ksh[nt]);
+                        b1[nt] += du;
+                        b2[nt] += du * (yv - kmu[nt]) * krs[nt];
+                    }
+                }
             }
         });
+        if constexpr (EPI == EPI_PLAIN) {
+            if (bnb) {   // same wave-shuffle -> LDS -> plain-store scheme as the forward statistics
+                float* red = (float*)smem;  // [2][BM/64][BN]
+                constexpr int WMc = BM / 64;
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    b1[i] += __shfl_xor(b1[i], 32);
+                    b2[i] += __shfl_xor(b2[i], 32);
+                    if (lane < 32) {
+                        red[(0 * WMc + wr) * BN + wcol0 + i * 32 + lane] = b1[i];
+                        red[(1 * WMc + wr) * BN + wcol0 + i * 32 + lane] = b2[i];
+                    }
+                }
+                __syncthreads();
+                if (tid < 2 * BN) {
+                    const int which = tid / BN, col = tid - which * BN;
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WMc; ++k) t += red[(which * WMc + k) * BN + col];
+                    const int n = n0 + col;
+                    if (n < p.N) {
+                        const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
+                        p.bnb_part[(((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)] = t;
+                    }
+                }
+            }
+        }
     } else {
         // bf16: transpose through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
@@ -366,7 +463,18 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         __syncthreads();
         constexpr int CPR = BN / 8;  // 16-B chunks per row
         constexpr int ITERS = BM * CPR / NT;
+        static_assert(NT % CPR == 0, "a thread keeps its column chunk over the store loop");
         bf16_t* out = (bf16_t*)p.out;
+        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
+        BnbCoef kc;
+        float b1[8], b2[8];
+        if constexpr (EPI == EPI_PLAIN) {
+            if (bnb) {
+                bnb_load(p, n0 + (tid % CPR) * 8, kc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = it * NT + tid;
@@ -381,7 +489,22 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
                 }
                 *(bf16x8*)(out + oi) = v;
+                if constexpr (EPI == EPI_PLAIN) {
+                    if (bnb) {
+                        const bf16x8 yv = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float yf = (float)yv[e];
+                            const float du = (float)v[e] * silu_grad(yf * kc.sc[e] + kc.sh[e]);
+                            b1[e] += du;
+                            b2[e] += du * (yf - kc.mu[e]) * kc.rs[e];
+                        }
+                    }
+                }
             }
+        }
+        if constexpr (EPI == EPI_PLAIN) {
+            if (bnb) bnb_finish<BN, NT, CPR>(p, (float*)smem, b1, b2, tid, mblk, n0);
         }
     }
 }
@@ -744,6 +867,16 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         __syncthreads();
         constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
         bf16_t* out = (bf16_t*)p.out;
+        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
+        BnbCoef kc;
+        float b1[8], b2[8];
+        if constexpr (EPI == EPI_PLAIN) {
+            if (bnb) {
+                bnb_load(p, n0 + (tid_e % CPR) * 8, kc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
+            }
+        }
 #pragma unroll 4
         for (int it = 0; it < ITERS; ++it) {
             const int c = it * NT + tid_e;
@@ -758,7 +891,22 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
                 }
                 *(bf16x8*)(out + oi) = v;
+                if constexpr (EPI == EPI_PLAIN) {
+                    if (bnb) {
+                        const bf16x8 yv = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float yf = (float)yv[e];
+                            const float du = (float)v[e] * silu_grad(yf * kc.sc[e] + kc.sh[e]);
+                            b1[e] += du;
+                            b2[e] += du * (yf - kc.mu[e]) * kc.rs[e];
+                        }
+                    }
+                }
             }
+        }
+        if constexpr (EPI == EPI_PLAIN) {
+            if (bnb) bnb_finish<BN, NT, CPR>(p, (float*)smem, b1, b2, tid_e, mblk, n0);
         }
     }
     stamp(3);
@@ -1216,7 +1364,36 @@ int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const
     return launch_igemm<EPI_HEAD>(d->dtype, p, (hipStream_t)stream);
 }
 
+// row blocks (BM of the tile the dispatcher picks) of ONE dgrad launch with m rows, n columns, reduction over c channels x ntaps
+static int dgrad_launch_rows(const fva_conv_desc* d, int64_t m, int n, int c, int ntaps, int64_t in_pixels) {
+    if (!halfrow_mode(d->dtype, c) && use_igemm8(d->dtype, m, n, c, ntaps, in_pixels)) return cdiv(m, 256);
+    return cdiv(m, tile_bm(d->dtype, (int)m, n));
+}
+
+int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d) {
+    if (!d || check_desc(d, "fva_conv_dgrad_stat_rows")) return 0;
+    const int k = d->ksize, s = d->stride;
+    const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
+    const int64_t in_pixels = (int64_t)(d->B + 1) * (OH + 2 * d->dy_pad) * (OW + 2 * d->dy_pad);
+    if (s == 1) return dgrad_launch_rows(d, (int64_t)d->B * d->H * d->W, d->Cin, d->Cout, k * k, in_pixels);
+    const int64_t mq = (int64_t)d->B * (d->H / 2) * (d->W / 2);
+    if (dgrad_paired(k, s, d->Cin)) {   // two launches (row parity) of N' = 2 * Cin columns: two table rows per block
+        int rows = 0;
+        for (int py = 0; py < 2; ++py) rows += 2 * dgrad_launch_rows(d, mq, 2 * d->Cin, d->Cout, py == 0 ? 2 : 4, in_pixels);
+        return rows;
+    }
+    int rows = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) rows += dgrad_launch_rows(d, mq, d->Cin, d->Cout, (py ? 2 : 1) * (px ? 2 : 1), in_pixels);
+    return rows;
+}
+
 int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream) {
+    return fva_conv_dgrad_bnstats(d, dy, w_dgrad, dx, addend, nullptr, stream);
+}
+
+int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
+                           const fva_bn_bwd_fuse* f, void* stream) {
     int rc = check_desc(d, "fva_conv_dgrad");
     if (rc) return rc;
     rc = check_red_channels(d->dtype, d->Cout, "fva_conv_dgrad");
@@ -1238,6 +1415,14 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
     p.sy = p.sx = 1;
     p.addend = addend;
     p.out_pitch = d->Cin;
+    if (f) {
+        if (!f->y || !f->scale || !f->shift || !f->mean || !f->rstd || !f->partial) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bnstats: null pointer");
+        p.bnb_y = f->y; p.bnb_scale = f->scale; p.bnb_shift = f->shift; p.bnb_mean = f->mean; p.bnb_rstd = f->rstd;
+        p.bnb_part = f->partial;
+        p.bnb_row0 = 0;
+        p.bnb_C = d->Cin;
+    }
+    const int64_t in_pixels = (int64_t)(d->B + 1) * (OH + 2 * d->dy_pad) * (OW + 2 * d->dy_pad);
     if (s == 1) {
         p.M = d->B * d->H * d->W;
         p.OW = d->W;
@@ -1289,6 +1474,7 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
             p.ooy = py;
             rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
             if (rc) return rc;
+            p.bnb_row0 += dgrad_launch_rows(d, p.M, p.N, p.C, nt, in_pixels);
         }
         return FVA_OK;
     }
@@ -1323,6 +1509,7 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
             p.oox = px;
             rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
             if (rc) return rc;
+            p.bnb_row0 += dgrad_launch_rows(d, p.M, p.N, p.C, nt, in_pixels);
         }
     return FVA_OK;
 }

@@ -240,13 +240,19 @@ __global__ void scatter_kernel(const MatchBuf mb, const Level lv, int32_t* cellm
 }
 
 // one wavefront per match: class BCE, CIoU box loss, IoU for the objectness target, and all their gradients
+// norm_count / norm_batch (data parallel, see fva_yolov3_loss_dp): the match count of this level and the batch size of the WHOLE job,
+// which the per-match means and the "* bs" of yolov3_loss.py:69-71 then refer to; the objectness term keeps the local batch
+// (its mean runs over cells, whose number per image is the same on every rank).
 __global__ __launch_bounds__(256) void match_loss_kernel(const MatchBuf mb, const Level lv, float* iou_out, float* box_l,
-                                                         float* cls_l, float ratio_box, float ratio_conf, float ratio_cls) {
+                                                         float* cls_l, float ratio_box, float ratio_conf, float ratio_cls,
+                                                         const int32_t* norm_count, int norm_batch) {
     const int n = *mb.count;
+    const int nn = norm_count ? *norm_count : n;     // denominator of the per-match means
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int C = lv.K - 5;
     const float fB = (float)lv.B;
+    const float fBn = norm_count ? (float)norm_batch : fB;
     const float ncell = (float)lv.B * lv.A * lv.H * lv.W;
     for (int m = blockIdx.x * wpb + (threadIdx.x >> 6); m < n; m += gridDim.x * wpb) {
         const int64_t b = mb.b[m];
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void match_loss_kernel(const MatchBuf mb, cons
         const int64_t base = b * lv.sb + mb.a[m] * lv.sa + mb.gy[m] * lv.sy + mb.gx[m] * lv.sx;
         const int cls = (int)mb.cls[m];
         // ---- class term: BCE on probabilities with 1e-8 inside the logs (classification_loss.py:54), mean over M*C
-        const float gc = ratio_cls * fB / ((float)n * (float)C);
+        const float gc = ratio_cls * fBn / ((float)nn * (float)C);
         float lsum = 0.f;
         for (int k = lane; k < C; k += 64) {
             const float z = lv.data[base + (5 + k) * lv.sk];
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void match_loss_kernel(const MatchBuf mb, cons
                 // d total / d tau for this cell (yolov3_loss.py:60-64): the IoU target is not detached
                 const float pc = sigm(zc);
                 const float gtau = (-logf(pc + BCE_EPS) + logf(1.f - pc + BCE_EPS)) * (ratio_conf * fB / ncell);
-                const float gb = ratio_box * fB / (float)n;
+                const float gb = ratio_box * fBn / (float)nn;
                 const float dpdz[4] = {px * (1.f - px), py * (1.f - py), pw, ph};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -331,6 +337,8 @@ struct FinalArgs {
     int C[4];
     int nlevels;
     int B;
+    const int32_t* norm_counts;   // data parallel: [nlevels] job-wide match counts, or null
+    int norm_batch;
 };
 __global__ __launch_bounds__(256) void yolo_final_kernel(const FinalArgs fa, float rb, float rc, float rcls, float* out) {
     __shared__ double red[3][256];
@@ -345,9 +353,10 @@ __global__ __launch_bounds__(256) void yolo_final_kernel(const FinalArgs fa, flo
         if (threadIdx.x == 0) {
             sb = sc = sf = 0.0;
             for (int i = 0; i < 256; ++i) { sb += red[0][i]; sc += red[1][i]; sf += red[2][i]; }
-            if (n > 0) {
-                lbox += sb / n;
-                lcls += sc / ((double)n * fa.C[l]);
+            const int nn = fa.norm_counts ? fa.norm_counts[l] : n;
+            if (n > 0 && nn > 0) {
+                lbox += sb / nn;
+                lcls += sc / ((double)nn * fa.C[l]);
             }
             lconf += sf / fa.ncell[l];
         }
@@ -357,7 +366,9 @@ __global__ __launch_bounds__(256) void yolo_final_kernel(const FinalArgs fa, flo
         out[1] = (float)lbox;
         out[2] = (float)lconf;
         out[3] = (float)lcls;
-        out[0] = (float)((lbox * rb + lconf * rc + lcls * rcls) * fa.B);
+        // data parallel: this rank's SHARE of the job-wide loss (the shares add up to the loss nn.DataParallel computes on the gathered batch)
+        out[0] = fa.norm_counts ? (float)((lbox * rb + lcls * rcls) * fa.norm_batch + lconf * rc * fa.B)
+                                : (float)((lbox * rb + lconf * rc + lcls * rcls) * fa.B);
     }
 }
 
@@ -635,14 +646,23 @@ int64_t fva_yolov3_loss_workspace(int32_t T, const fva_head_level* levels, int32
 
 int fva_yolov3_loss(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels, float ratio_box,
                     float ratio_conf, float ratio_cls, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    return fva_yolov3_loss_dp(targets, T, levels, nlevels, ratio_box, ratio_conf, ratio_cls, nullptr, 0, loss_out, workspace, workspace_bytes, stream);
+}
+
+int fva_yolov3_loss_dp(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels, float ratio_box,
+                       float ratio_conf, float ratio_cls, const int32_t* norm_counts, int32_t norm_batch, float* loss_out, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
     if (!levels || nlevels < 1 || nlevels > 4 || !loss_out || !workspace || (T > 0 && !targets))
         return fva_fail(FVA_ERR_ARG, "fva_yolov3_loss: bad argument");
+    if (norm_counts && norm_batch < levels[0].B) return fva_fail(FVA_ERR_ARG, "fva_yolov3_loss_dp: job batch %d smaller than the local batch %d", norm_batch, levels[0].B);
     if (workspace_bytes < fva_yolov3_loss_workspace(T, levels, nlevels)) return fva_fail(FVA_ERR_WORKSPACE, "fva_yolov3_loss: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver c{(char*)workspace};
     FinalArgs fa = FinalArgs();
     fa.nlevels = nlevels;
     fa.B = levels[0].B;
+    fa.norm_counts = norm_counts;
+    fa.norm_batch = norm_batch;
     for (int l = 0; l < nlevels; ++l) {
         int rc = check_level(levels[l], "fva_yolov3_loss");
         if (rc) return rc;
@@ -662,7 +682,7 @@ int fva_yolov3_loss(const float* targets, int32_t T, const fva_head_level* level
             hipLaunchKernelGGL(scatter_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, s, mb, lv, cellmatch);
             FVA_LAUNCH_CHECK("scatter_kernel");
             hipLaunchKernelGGL(match_loss_kernel, dim3(cdiv(cap, 4) < 2048 ? cdiv(cap, 4) : 2048), dim3(256), 0, s, mb, lv, iou, box_l,
-                               cls_l, ratio_box, ratio_conf, ratio_cls);
+                               cls_l, ratio_box, ratio_conf, ratio_cls, norm_counts ? norm_counts + l : nullptr, norm_batch);
             FVA_LAUNCH_CHECK("match_loss_kernel");
         }
         const int cblocks = (int)((ncell + 255) / 256 < CONF_BLOCKS ? (ncell + 255) / 256 : CONF_BLOCKS);

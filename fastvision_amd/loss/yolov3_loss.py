@@ -32,11 +32,32 @@ def _as_f32(h):
     return h if h.dtype == torch.float32 else h.float()
 
 
+def job_match_counts(targets, hs, anchors, strides, group):
+    """[levels] int32 on the device: matches per level summed over every rank of ``group`` (three tiny matcher launches and one
+    12-byte all-reduce, enqueued on the current stream -- no host sync)."""
+    import torch.distributed as dist
+    dev, T = hs[0].device, targets.shape[0]
+    counts = torch.zeros(len(hs), dtype=torch.int32, device=dev)
+    keep = []
+    for lvl, h in enumerate(hs):
+        A = len(anchors[lvl])
+        cap = max(T * A, 1)
+        i64 = torch.empty((5, cap), dtype=torch.int64, device=dev)
+        f32 = torch.empty(cap * 6, dtype=torch.float32, device=dev)
+        lv = make_level(h, None, anchors[lvl], strides[lvl])
+        mo = _lib.MatchOut(counts[lvl:].data_ptr(), i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), i64[3].data_ptr(),
+                           i64[4].data_ptr(), f32.data_ptr(), f32[cap * 4:].data_ptr())
+        keep.append((i64, f32))
+        _lib.call('fva_yolov3_match', _p(targets) if T else C.c_void_p(0), T, C.byref(lv), C.byref(mo), _stream())
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
 class _Yolov3LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, targets, anchors, strides, ratios, *heads):
+    def forward(ctx, targets, anchors, strides, ratios, dp, *heads):
         hs = [_as_f32(h.detach()) for h in heads]
-        need = any(ctx.needs_input_grad[4:])
+        need = any(ctx.needs_input_grad[5:])
         grads = []
         levels = (_lib.HeadLevel * len(hs))()
         for i, h in enumerate(hs):
@@ -53,8 +74,14 @@ class _Yolov3LossFn(torch.autograd.Function):
         wsb = lib.fva_yolov3_loss_workspace(T, levels, len(hs))
         ws = torch.empty(wsb, dtype=torch.uint8, device=hs[0].device)
         out = torch.empty(4, dtype=torch.float32, device=hs[0].device)
-        _lib.call('fva_yolov3_loss', _p(targets) if T else C.c_void_p(0), T, levels, len(hs), ratios[0], ratios[1], ratios[2],
-                  _p(out), _p(ws), wsb, _stream())
+        if dp is None:
+            _lib.call('fva_yolov3_loss', _p(targets) if T else C.c_void_p(0), T, levels, len(hs), ratios[0], ratios[1], ratios[2],
+                      _p(out), _p(ws), wsb, _stream())
+        else:
+            group, world = dp
+            counts = job_match_counts(targets, hs, anchors, strides, group)
+            _lib.call('fva_yolov3_loss_dp', _p(targets) if T else C.c_void_p(0), T, levels, len(hs), ratios[0], ratios[1], ratios[2],
+                      _p(counts), world * hs[0].shape[0], _p(out), _p(ws), wsb, _stream())
         ctx.grads = grads
         ctx.dtypes = [h.dtype for h in heads]
         ctx.parts = out
@@ -71,7 +98,7 @@ class _Yolov3LossFn(torch.autograd.Function):
                 continue
             g = g * gout            # scalar upstream gradient
             res.append(g if g.dtype == dt else g.to(dt))
-        return (None, None, None, None, *res)
+        return (None, None, None, None, None, *res)
 
 
 class Yolov3Loss(nn.Module):
@@ -86,6 +113,19 @@ class Yolov3Loss(nn.Module):
         self.ratio_box, self.ratio_conf, self.ratio_cls = ratio_box, ratio_conf, ratio_cls
         self._anchors_px = [[(float(w), float(h)) for w, h in a.reshape(-1, 2).tolist()] for a in self.anchor_levels]
         self.last_parts = None
+        self._dp = None
+
+    def data_parallel(self, group=None, enable=True):
+        """One process per GPU in place of the reference's nn.DataParallel: evaluate this rank's SHARE of the loss the reference
+        computes once on the batch gathered from all replicas (demos/yolov3_u/cfg/_fit.py:48-51, loss/yolov3_loss.py:69-71) --
+        per-match means over the job's match count, "* bs" with the job's batch.  Summing the shares (and SUM-reducing the
+        gradients: parallel.GradientReducer(average=False)) reproduces the reference's step; every rank must hold the same
+        number of images.  Returns self."""
+        import torch.distributed as dist
+        self._dp = None
+        if enable and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self._dp = (group, dist.get_world_size(group))
+        return self
 
     def _targets(self, y_true, like):
         require_gpu(like, 'Yolov3Loss')
@@ -94,7 +134,7 @@ class Yolov3Loss(nn.Module):
     def forward(self, y_pred, y_true):
         tg = self._targets(y_true, y_pred[0])
         loss, parts = _Yolov3LossFn.apply(tg, self._anchors_px, self.backbone_stride_levels,
-                                          (self.ratio_box, self.ratio_conf, self.ratio_cls), *y_pred)
+                                          (self.ratio_box, self.ratio_conf, self.ratio_cls), self._dp, *y_pred)
         self.last_parts = parts          # (box, conf, cls) means, device tensor, no sync
         return loss
 

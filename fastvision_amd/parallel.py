@@ -40,11 +40,21 @@ def init_from_env(backend=None):
 
 
 def broadcast_parameters(module, src=0, group=None):
-    """Make every rank start from rank ``src``'s parameters and buffers (DataParallel replicates from GPU 0)."""
+    """Make every rank start from rank ``src``'s parameters and buffers (DataParallel replicates from GPU 0).
+    One flat broadcast per (dtype, device) -- two collectives for YOLOv3 (fp32 tensors, the int64 batch counters) instead of
+    one per tensor (438 + 72)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    groups = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        groups.setdefault((t.dtype, t.device), []).append(t.data)
+    for ts in groups.values():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
 
 def shard_targets(targets, rank, per_rank_batch):
@@ -65,17 +75,27 @@ class GradientReducer:
         optimizer.step()
 
     Buckets are launched strictly in index order so that every rank issues the same sequence of collectives.
+
+    ``average``: True divides the summed gradient by the world size (right for a loss that is a MEAN over the batch, the demo's
+    ComputeLoss); False leaves the SUM (right for the library's Yolov3Loss, which multiplies its means by the batch size,
+    loss/yolov3_loss.py:69-71: under the reference's nn.DataParallel that loss sees the gathered batch of N*b images, whose
+    gradient is the sum of the per-rank ``* b`` losses' gradients -- an average would be 1/N of it and make Adam's folded-in weight
+    decay and eps N times stronger; see ``loss_normalisation``).
+    ``bucket_dtype``: dtype the gradients travel in (default: the parameters' own, fp32).  torch.bfloat16 halves the bytes on the
+    xGMI links (124 MB instead of 248 MB per step for YOLOv3); the optimizer reads the bf16 buckets (FusedAdam accepts them).
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True):
-        self.group, self.average = group, average
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True, bucket_dtype=None):
+        self.group, self.average, self.bucket_dtype = group, average, bucket_dtype
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world == 1:
+            self.bucket_dtype = None                      # nothing travels
         self.params = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))               # backward produces gradients roughly in reverse order
         self.buckets, self.where = [], {}
         cur, cur_bytes = [], 0
         for p in order:
-            nbytes = p.numel() * p.element_size()
+            nbytes = p.numel() * (p.element_size() if bucket_dtype is None else torch.empty(0, dtype=bucket_dtype).element_size())
             if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
                 self._close(cur)
                 cur, cur_bytes = [], 0
@@ -90,13 +110,18 @@ class GradientReducer:
         self.reset()
 
     def _close(self, plist):
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
-        views, off = [], 0
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        # the buffer that travels: the fp32 bucket itself, or a narrower copy of it (p.grad must keep the parameter's dtype, so
+        # the optimizer-facing views stay fp32 and finish() widens the reduced wire buffer back into them: 0.1 ms for 62 M values)
+        wire = flat if self.bucket_dtype in (None, flat.dtype) else torch.zeros(n, dtype=self.bucket_dtype, device=flat.device)
+        views, wviews, off = [], [], 0
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
+            wviews.append(wire[off:off + p.numel()].view_as(p))
             self.where[p] = (len(self.buckets), len(views) - 1)
             off += p.numel()
-        self.buckets.append((flat, plist, views))
+        self.buckets.append((flat, plist, views, wire, wviews))
 
     def reset(self):
         self.pending = [len(b[1]) for b in self.buckets]
@@ -116,14 +141,16 @@ class GradientReducer:
 
     def _on_grad(self, p):
         bi, vi = self.where[p]
-        view = self.buckets[bi][2][vi]
+        view, wview = self.buckets[bi][2][vi], self.buckets[bi][4][vi]
         with self._side(p):
             if p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
+                wview.copy_(p.grad)
                 if p.is_cuda:
                     from .ops import hold_for_side_stream
                     hold_for_side_stream(p.grad)           # still being written / read on the side stream
-                p.grad = view                              # the optimizer reads the (soon averaged) bucket
+                p.grad = view                              # the optimizer reads the (soon reduced) bucket
+            elif wview.data_ptr() != view.data_ptr():
+                wview.copy_(view)
             self.pending[bi] -= 1
             self._launch_ready()
 
@@ -135,7 +162,7 @@ class GradientReducer:
     def _launch(self, bi):
         if self.world == 1:
             return
-        flat = self.buckets[bi][0]
+        flat = self.buckets[bi][3]
         backend = dist.get_backend(self.group)
         if self.average and backend == 'nccl':
             self.handles[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False)
@@ -149,21 +176,24 @@ class GradientReducer:
             from .ops import join_side_stream
             join_side_stream(force=True)
         for bi in range(self.next_launch, len(self.buckets)):
-            flat, plist, views = self.buckets[bi]
-            for p, v in zip(plist, views):
+            flat, plist, views, wire, wviews = self.buckets[bi]
+            for p, v, wv in zip(plist, views, wviews):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     if p.grad is None:
-                        v.zero_()
+                        wv.zero_()
                     else:
-                        v.copy_(p.grad)
+                        wv.copy_(p.grad)
                     p.grad = v
             self._launch(bi)
         self.next_launch = len(self.buckets)
         for bi, h in enumerate(self.handles):
             if h is not None:
                 h[0].wait()
+                flat, wire = self.buckets[bi][0], self.buckets[bi][3]
                 if h[1]:
-                    self.buckets[bi][0].div_(self.world)
+                    wire.div_(self.world)
+                if wire.data_ptr() != flat.data_ptr():
+                    flat.copy_(wire)
         self.reset()
 
     def remove(self):

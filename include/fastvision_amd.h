@@ -254,6 +254,17 @@ int fva_yolov3_loss(const float* targets, int32_t T, const fva_head_level* level
                     void* workspace, int64_t workspace_bytes, void* stream);
 int64_t fva_yolov3_loss_workspace(int32_t T, const fva_head_level* levels, int32_t nlevels);
 
+/* Data-parallel form of the same loss.  The reference wraps the model in nn.DataParallel (demos/yolov3_u/train.py:85) and
+ * evaluates yolov3_loss.py:29-72 ONCE on the batch gathered from all N replicas: its per-match means divide by the match count
+ * of the whole job and its result is multiplied by the job's batch size.  With one process per GPU each rank calls this entry on
+ * its own images and targets with norm_counts[nlevels] = the per-level match counts summed over all ranks (device memory: run
+ * fva_yolov3_match per level, all-reduce the three counts) and norm_batch = N * B: loss_out[0] is then this rank's SHARE of that
+ * loss and level.grad its gradient, so that a SUM all-reduce of the parameter gradients (and of loss_out[0]) reproduces the
+ * reference's step.  norm_counts == NULL: plain fva_yolov3_loss. */
+int fva_yolov3_loss_dp(const float* targets, int32_t T, const fva_head_level* levels, int32_t nlevels,
+                       float ratio_box, float ratio_conf, float ratio_cls, const int32_t* norm_counts, int32_t norm_batch,
+                       float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Demo loss (demos/yolov3_u/utils/lossv3.py:18-119): best-anchor assignment, BCE/MSE/BCE terms, IoU>0.5
  * ignore mask, masked objectness BCE.  level.anchor_* are FEATURE-scale here and level.stride is unused.
  * loss_out[5] = {total, xy, wh, cls, conf} (unweighted parts, as the reference prints them). */
