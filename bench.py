@@ -45,32 +45,48 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(size, budget_s=25.0):
-    """Time the CPU oracle on a bounded sample of the same workload: one image of the same size per step."""
+def cpu_baseline(size, batch, budget_s=75.0):
+    """Time the CPU oracle (port of the reference's CPU path, utils/fit.py:47-71) on this host's cores, BASELINE.md section 4:
+    the bench workload itself -- ``batch`` x 3 x size x size, fp32, 1 warm-up + up to 2 timed steps on all cores this process may
+    use -- plus a 1-thread figure on one image of the same size.  Bounded: when the warm-up step says a timed step would not fit
+    the budget, the warm-up is the sample; when even that is out of reach (a small host), one image per step is timed instead
+    and flagged ``port-sample``."""
     from oracle import train as otrain
     from fastvision_amd.synthetic import synthetic_batch
     cores = usable_cores()
+
+    def run(b, threads, max_timed, budget):
+        torch.set_num_threads(threads)
+        images, tg = synthetic_batch(b, size)
+        net, crit = otrain.make_library(20220504)
+        opt = otrain.make_adam(net)
+        print(f'[bench] cpu_baseline: oracle on {threads} thread(s), {b}x3x{size}x{size} ...', file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        _, tw = otrain.train_steps(net, crit, opt, images, tg, 1)          # warm-up (also bounds the cost of a step)
+        print(f'[bench] cpu_baseline: warm-up step {tw[0]:.2f} s', file=sys.stderr, flush=True)
+        times = []
+        while len(times) < max_timed and time.perf_counter() - t0 + tw[0] < budget:
+            _, t = otrain.train_steps(net, crit, opt, images, tg, 1)
+            times.append(t[0])
+            print(f'[bench] cpu_baseline: step {len(times)} {t[0]:.2f} s', file=sys.stderr, flush=True)
+        warm_only = not times
+        med = sorted(times or tw)[len(times or tw) // 2]
+        return med, ('warm-up step only' if warm_only else f'1 warm-up + {len(times)} timed steps')
+    try:
+        mem_gb = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES') / 2 ** 30
+    except (ValueError, OSError):
+        mem_gb = 0.0
+    full = mem_gb >= 2.5 * batch * (size / 640.0) ** 2 + 8          # the fp32 autograd state of the oracle is ~2 GB per 640 px image
+    b = batch if full else 1
+    med, what = run(b, cores, 2, budget_s)
+    out = {'value': round(b / med, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port' if full else 'port-sample',
+           'sample': f'CPU oracle (port of the reference CPU path: same model, yolov3_loss, Adam, utils/fit.py step), fp32, {what} of '
+                     f'{b}x3x{size}x{size}, median {med:.2f} s/step, torch threads = {cores}'}
+    med1, what1 = run(1, 1, 1, 25.0)
+    out['one_thread'] = {'value': round(1.0 / med1, 4), 'unit': 'images/sec', 'cores': 1,
+                         'sample': f'{what1} of 1x3x{size}x{size}, median {med1:.2f} s/step, 1 torch thread'}
     torch.set_num_threads(cores)
-    batch = 1
-    images, tg = synthetic_batch(batch, size)
-    net, crit = otrain.make_library(20220504)
-    opt = otrain.make_adam(net)
-    print(f'[bench] cpu_baseline: oracle on {cores} threads, {batch}x3x{size}x{size} ...', file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    _, tw = otrain.train_steps(net, crit, opt, images, tg, 1)          # warm-up (also bounds the cost of a step)
-    times = []
-    while len(times) < 3 and time.perf_counter() - t0 + tw[0] < budget_s:
-        _, t = otrain.train_steps(net, crit, opt, images, tg, 1)
-        times.append(t[0])
-        print(f'[bench] cpu_baseline: step {len(times)} {t[0]:.2f} s', file=sys.stderr, flush=True)
-    warm_only = not times
-    if warm_only:
-        times = tw
-    med = sorted(times)[len(times) // 2]
-    return {'value': round(batch / med, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'CPU oracle (port of the reference CPU path: same model, yolov3_loss, Adam, utils/fit.py step), fp32, '
-                      f'{"warm-up step only" if warm_only else f"1 warm-up + {len(times)} timed steps"} of '
-                      f'{batch}x3x{size}x{size}, median {med:.2f} s/step, torch threads = {cores}'}
+    return out
 
 
 def spawn_ranks(n):
@@ -149,8 +165,9 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-graph', action='store_true', help='issue every step eagerly from Python instead of replaying a captured HIP graph')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
@@ -195,13 +212,23 @@ def main():
         cl = ComputeLoss()
         loss_fn = lambda pred, tg: cl(pred, tg, net)
     parallel.broadcast_parameters(net)
-    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
-    reducer = parallel.GradientReducer(net.parameters()) if world > 1 else None
+    # One GPU: the whole step is captured in a HIP graph and replayed (graphs.GraphedTrainStep) -- the host issues one launch per
+    # step instead of ~900 C-ABI calls.  N > 1 stays eager: the gradient buckets' collectives are launched from autograd hooks.
+    use_graph = world == 1 and not args.no_graph and not args.shapes
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4, capturable=use_graph)
+    reducer = None
+    if world > 1:
+        # the library loss is "(means) * batch" (loss/yolov3_loss.py:69-71): under the reference's DataParallel it sees the gathered
+        # batch, so the ranks' shares are SUMMED (job-wide match counts in the loss kernel); the demo loss is a plain mean: AVG
+        lib_surface = args.surface == 'lib'
+        if lib_surface:
+            crit.data_parallel()
+        reducer = parallel.GradientReducer(net.parameters(), average=not lib_surface, bucket_dtype=torch.bfloat16)
 
     images, targets = synthetic_batch(args.batch, args.size, rank=rank)     # per-rank shard of the global batch (weak scaling)
     images, targets = images.to(dev), targets.to(dev)
 
-    def step():
+    def eager_step():
         pred = net(images)
         opt.zero_grad()
         loss = loss_fn(pred, targets)
@@ -210,6 +237,7 @@ def main():
             reducer.finish()
         opt.step()
         return loss
+    step = eager_step
 
     def fence():
         if world > 1:
@@ -225,6 +253,82 @@ def main():
             calls_per_step = cc.calls
         else:
             step()
+    fence()
+    # untimed probe for the informative `kernels` table: all three convolution classes bracketed with HIP events inside the
+    # library, issued eagerly with the weight gradients on the launch stream like everything else, so that every launch has the
+    # GPU to itself (exclusive durations).  In the product configuration the wgrad launches run on the library's low-priority
+    # side stream, concurrently with the rest of the backward pass: event-to-event durations of wgrad and dgrad launches then
+    # include time spent sharing the GPU.
+    from fastvision_amd import ops as fva_ops
+    probe_steps = 3
+    side_was = fva_ops.set_wgrad_side_stream(False)
+    step()
+    with KernelTimer(pool=calls_per_step * probe_steps + 8) as probe:
+        for _ in range(probe_steps):
+            step()
+        fence()
+    # the shader clock under load: MI355X runs its matrix pipes well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at.
+    # One more untimed step with the 8-phase kernel's diagnostic stamps on: cycle counter / wall clock over each block's
+    # k-loop (bf16 only -- the 8-phase kernel is a bf16 kernel).
+    clock_mhz = None
+    import ctypes as C
+    from fastvision_amd import _lib as fva_lib
+    if args.dtype == 'bf16':
+        nstamp = 8192
+        stamps = torch.zeros(8 * nstamp, dtype=torch.int64, device=dev)
+        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(stamps.data_ptr()), nstamp)
+        step()
+        fence()
+        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(0), 0)
+        st = stamps.view(-1, 8).cpu()
+        st = st[st[:, 3] > 0]
+        if len(st):
+            wall_us = (st[:, 2] - st[:, 1]).double() / 100.0
+            clock_mhz = float(((st[:, 6] - st[:, 5]).double() / wall_us).median())
+    fva_ops.set_wgrad_side_stream(side_was)
+    probe_summ = probe.summary()
+    dom = 'conv_fwd'
+
+    # The side stream is the product default, but whether two HIP streams (or two branches of a graph) share the GPU to advantage
+    # depends on the box and on the collective backend: time three steps each way and keep the faster setting (collectively).
+    graph_info = None
+    if use_graph:
+        from fastvision_amd.graphs import GraphedTrainStep
+
+        def capture(side_on, spans=False):
+            fva_ops.set_wgrad_side_stream(side_on)
+
+            def arm():      # the roofline class bracketed by event-record nodes inside the captured sequence
+                fva_lib.call('fva_profile_classes', 1, 1)
+                fva_lib.call('fva_profile_start', calls_per_step + 8)
+            return GraphedTrainStep(net, loss_fn, opt, images, targets, warmup=1, on_capture=arm if spans else None)
+
+        def window(fn, n=3):
+            fence()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return (time.perf_counter() - t) / n * 1e3
+        side_check, cand = {}, {}
+        t_cap = time.perf_counter()
+        for name, on in (('off', False), ('on', True)):
+            if on and not side_was:
+                continue
+            cand[name] = capture(on)
+            cand[name]()
+            side_check[name] = round(window(cand[name]), 3)
+        side_use = 'on' in cand and side_check['on'] <= side_check['off']
+        gstep = cand['on' if side_use else 'off']
+        cand.clear()
+        fva_ops.set_wgrad_side_stream(side_use)
+        step = gstep
+        graph_info = {'capture_s': round(time.perf_counter() - t_cap, 2)}
+    else:
+        side_check = fva_ops.autotune_wgrad_side_stream(step, fence, steps=3)
+        side_use = side_check.pop('use')
+        fva_ops.set_wgrad_side_stream(side_use)
+    step()
     fence()
     # settle: a freshly started process can run its first steps at a different pace (allocator growth, clocks, a busy
     # host); keep stepping, untimed, until two consecutive 3-step windows agree within 5 % (at most 6 windows)
@@ -245,58 +349,26 @@ def main():
         if prev is not None and abs(w - prev) <= 0.05 * min(w, prev):
             break
         prev = w
-    # untimed probe for the informative `kernels` table: all three convolution classes bracketed, with the weight gradients
-    # on the launch stream like everything else, so that every launch has the GPU to itself (exclusive durations).
-    # In the timed region the wgrad launches run on the library's low-priority side stream, concurrently with the rest of
-    # the backward pass: event-to-event durations of wgrad and dgrad launches then include time spent sharing the GPU.  The
-    # dominant kernel is the implicit-GEMM convolution (igemm8_kernel / igemm_kernel: forward + dgrad instances = 2/3 of the
-    # convolution time); the roofline figure is measured live on its FORWARD launches, the ones that still run alone.
-    # Only that class is bracketed in the timed region -- every span costs two event packets on the stream.
-    from fastvision_amd import ops as fva_ops
-    probe_steps = 3
-    side_was = fva_ops.set_wgrad_side_stream(False)
-    step()
-    with KernelTimer(pool=calls_per_step * probe_steps + 8) as probe:
-        for _ in range(probe_steps):
-            step()
-        fence()
-    # the shader clock under load: MI355X runs its matrix pipes well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at.
-    # One more untimed step with the 8-phase kernel's diagnostic stamps on: cycle counter / wall clock over each block's
-    # k-loop (bf16 only -- the 8-phase kernel is a bf16 kernel).
-    clock_mhz = None
-    if args.dtype == 'bf16':
-        import ctypes as C
-        from fastvision_amd import _lib as fva_lib
-        stamps = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
-        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(stamps.data_ptr()))
-        step()
-        fence()
-        fva_lib.call('fva_conv_debug_stamps', C.c_void_p(0))
-        st = stamps.view(-1, 8).cpu()
-        st = st[st[:, 3] > 0]
-        if len(st):
-            wall_us = (st[:, 2] - st[:, 1]).double() / 100.0
-            clock_mhz = float(((st[:, 6] - st[:, 5]).double() / wall_us).median())
-    # The side stream is the product default, but whether two HIP streams share the GPU to advantage depends on the box and on
-    # the collective backend: the library times three steps each way and keeps the faster setting (collectively).
-    fva_ops.set_wgrad_side_stream(side_was)
-    side_check = fva_ops.autotune_wgrad_side_stream(step, fence, steps=3)
-    side_use = side_check.pop('use')
-    fva_ops.set_wgrad_side_stream(side_use)
-    step()
-    fence()
-    probe_summ = probe.summary()
-    dom = 'conv_fwd'
-    # events exist before the clock starts; --shapes needs the Python-side tracer (it keeps each call's layer shape)
-    SAMPLE_STRIDE = 7          # coprime to the 74 forward launches of a step: the sample walks through all layers
-    timer = PyKernelTimer(pool=calls_per_step * args.steps + 8) if args.shapes else \
-        KernelTimer(pool=calls_per_step * args.steps + 8, classes=[dom], stride=SAMPLE_STRIDE)
+    # The dominant kernel is the implicit-GEMM convolution (igemm8_kernel / igemm_kernel: forward + dgrad instances = 2/3 of the
+    # convolution time); its roofline figure is measured live with HIP events on its FORWARD launches -- the instances that run
+    # alone on the device (dgrad and wgrad launches share the GPU in the product configuration, so their event-to-event
+    # durations say nothing about the kernel).  Eager: every 7th forward launch is bracketed inside the timed region (a span
+    # costs two event packets on the stream; 7 is coprime to the 74 launches of a step, so the sample walks through all layers).
+    # Graph: the timed region replays the product graph untouched; straight after it a second capture of the same step, with an
+    # event-record node before and after every forward launch, is replayed and read out.
+    SAMPLE_STRIDE = 7
+    if use_graph:
+        timer = None
+    else:
+        timer = PyKernelTimer(pool=calls_per_step * args.steps + 8) if args.shapes else \
+            KernelTimer(pool=calls_per_step * args.steps + 8, classes=[dom], stride=SAMPLE_STRIDE)
     fence()
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: where the time goes
     # Python's cyclic garbage collector: a generation-2 pass over everything this process has built (modules, the oracle's
     # imports, autograd graphs) stops the launching thread for 0.2-0.3 s -- ten steps' worth of queued GPU work runs dry.
     # Collect now, then freeze the survivors into the permanent generation so that later passes only look at new objects;
     # pauses that still happen inside the timed region are recorded.
+    import contextlib
     import gc
     gc_log, gc_t = [], [0.0]
 
@@ -308,7 +380,7 @@ def main():
     gc.collect()
     gc.freeze()
     gc.callbacks.append(gc_watch)
-    with timer as kt:
+    with (timer if timer is not None else contextlib.nullcontext()) as kt:
         t0 = time.perf_counter()
         step_marks[0].record()
         for i in range(args.steps):
@@ -318,14 +390,46 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     gc.callbacks.remove(gc_watch)
+    final_loss = float(loss.detach())
+    roof_how = 'every launch' if args.shapes else f'every {SAMPLE_STRIDE}th launch of the class over the timed region'
+    if use_graph:
+        # the same step captured with event-record nodes around every forward convolution launch, replayed right after the
+        # timed region; falls back to eagerly issued steps if this runtime does not time events recorded by graph nodes
+        summ = None
+        try:
+            if os.environ.get('FVA_BENCH_GRAPH_SPANS', '1') == '0':
+                raise RuntimeError('switched off (FVA_BENCH_GRAPH_SPANS=0)')
+            gspan = capture(side_use, spans=True)
+            for _ in range(3):
+                gspan()
+            fence()
+            kt = KernelTimer(pool=calls_per_step + 8, classes=[dom], stride=1)
+            kt._collect()
+            cand_summ = kt.summary()
+            d0 = cand_summ.get(dom)
+            if d0 and d0['launches'] >= 10 and 0.2 * probe_summ[dom]['ms_total'] / probe_steps < d0['ms_total'] < 5 * probe_summ[dom]['ms_total'] / probe_steps:
+                summ = cand_summ
+                roof_how = 'event-record nodes around every forward launch of the captured step, replay right after the timed region'
+            del gspan
+        except RuntimeError as e:
+            print(f'[bench] spans inside the graph unavailable: {e}', file=sys.stderr)
+            fva_lib.load().fva_profile_stop(None, None, None, 0)
+        if summ is None:
+            fva_ops.set_wgrad_side_stream(side_use)
+            with KernelTimer(pool=calls_per_step * 3 + 8, classes=[dom], stride=1) as kt:
+                for _ in range(3):
+                    eager_step()
+                fence()
+            summ = kt.summary()
+            roof_how = 'every forward launch of 3 eagerly issued steps right after the timed region (graph replays carry no events)'
+    else:
+        summ = kt.summary()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss.detach())
 
     if rank == 0:
-        summ = kt.summary()
         ms_step = elapsed / args.steps * 1e3
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
@@ -357,7 +461,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': kernel_name, 'achieved': round(d['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(d['tflops'] / peak, 4), 'traffic': traffic,
                          'launches_per_step': probe_summ[dom]['launches'] // probe_steps, 'launches_timed': d['launches'],
-                         'sampling': 'every launch' if args.shapes else f'every {SAMPLE_STRIDE}th launch of the class over the timed region',
+                         'sampling': roof_how,
                          'avg_launch_ms': round(d['ms_avg'], 4), 'gflop_per_launch': round(d['flop_per_launch'] / 1e9, 3),
                          'ms_per_step': round(probe_summ[dom]['ms_total'] / probe_steps, 3),
                          'shader_clock_mhz_under_load': None if clock_mhz is None else round(clock_mhz),
@@ -372,6 +476,7 @@ def main():
                             'timed region, with the weight gradients on the launch stream (in the timed region they run on a '
                             'low-priority side stream beside the rest of backward, and only the roofline class is bracketed)',
             'wgrad_side_stream': bool(side_use), 'side_stream_check_ms_per_step': side_check,
+            'hip_graph': graph_info if use_graph else False,
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
             'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
             'step_ms': [round(step_marks[i].elapsed_time(step_marks[i + 1]), 2) for i in range(args.steps)],
@@ -382,7 +487,7 @@ def main():
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):
                 print(f'{k}: launches {v[0]} ms_total {v[1]:.3f} tflops {v[2]:.1f}', file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.size)
+            out['cpu_baseline'] = cpu_baseline(args.size, args.batch)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

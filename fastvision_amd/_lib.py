@@ -42,6 +42,10 @@ class PasteJob(C.Structure):
                [('scale_x', C.c_double), ('scale_y', C.c_double)]
 
 
+class BnBwdFuse(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('y', 'scale', 'shift', 'mean', 'rstd', 'partial')]
+
+
 class MatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
 
@@ -58,7 +62,7 @@ PROTOTYPES = {
     'fva_profile_classes': (_I, [C.c_uint32, _I]),
     'fva_side_stream_fork': (_I, [_P, C.POINTER(C.c_void_p)]),
     'fva_side_stream_join': (_I, [_P]),
-    'fva_conv_debug_stamps': (_I, [_P]),
+    'fva_conv_debug_stamps': (_I, [_P, _I]),
     'fva_profile_stop': (_I, [_P, _P, _P, _I]),
     'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
     'fva_conv_packed_elems': (_L, [_D, _I]),
@@ -70,6 +74,8 @@ PROTOTYPES = {
     'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv_dgrad_bnstats': (_I, [_D, _P, _P, _P, _P, C.POINTER(BnBwdFuse), _P]),
+    'fva_conv_dgrad_stat_rows': (_I, [_D]),
     'fva_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _L, _P]),
     'fva_conv_wgrad_workspace': (_L, [_D]),
     'fva_stem_fwd': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
@@ -105,6 +111,7 @@ PROTOTYPES = {
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),
     'fva_iou_batch': (_I, [_I, _I, _I, _P, _P, _P, _L, _L, _F, _P]),
     'fva_adam_step': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
+    'fva_adam_step_dev': (_I, [_P, _P, _I, _L, _P, _F, _F, _F, _F, _P, _F, _P]),
     'fva_paste_resize_normalize': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'fva_paste_resize_u8': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'fva_yolo_decode': (_I, [_H, _I, _I, C.POINTER(Letterbox), _P, _L, _P]),
@@ -125,7 +132,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

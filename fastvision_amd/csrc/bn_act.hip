@@ -228,12 +228,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, double count, int C,
                                                                const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                                               float* dgamma, float* dbeta, int accumulate, float* coef) {
+                                                               float* dgamma, float* dbeta, int accumulate, float* coef,
+                                                               const double* __restrict__ pre, int pre_rows) {
     __shared__ double red[2][FIN_G][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) reduce_partials(part, nblocks, C, c, ry, s1, s2);
+    if (c < C) {
+        if (pre_rows > 0) {
+            for (int r = ry; r < pre_rows; r += FIN_G) {
+                s1 += pre[((int64_t)r * 2 + 0) * C + c];
+                s2 += pre[((int64_t)r * 2 + 1) * C + c];
+            }
+        } else {
+            reduce_partials(part, nblocks, C, c, ry, s1, s2);
+        }
+    }
     red[0][ry][cx] = s1;
     red[1][ry][cx] = s2;
     __syncthreads();
@@ -511,12 +521,24 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
     return FVA_OK;
 }
 
-int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C, const float* gamma, const float* save_rstd,
+int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int64_t M, int C, const float* gamma, const float* save_rstd,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
     if (!partial || !gamma || !save_rstd || !dgamma || !dbeta || !coef || nblocks <= 0 || M <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_bwd_finalize: bad argument");
+    // tables of the fused dgrad epilogues can be long (one row per 128- or 256-pixel block): beyond what fva_bn_silu_bwd_reduce
+    // writes (<= 2048 rows) they are first folded in parallel, as in the forward pass (the caller allocated
+    // fva_bn_partial_rows(nblocks) rows: the doubles live behind the table)
+    const double* pre = nullptr;
+    int pre_rows = 0;
+    if (nblocks > 2048) {
+        pre_rows = cdiv(nblocks, PRE_ROWS);
+        double* tail = (double*)(partial + ((int64_t)nblocks * 2 * C + 1) / 2 * 2);
+        pre = tail;
+        hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(C, 16), pre_rows), dim3(1024), 0, (hipStream_t)stream, partial, nblocks, C, tail);
+        FVA_LAUNCH_CHECK("bn_prereduce_kernel");
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, partial, nblocks, (double)M, C,
-                       gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+                       gamma, save_rstd, dgamma, dbeta, accumulate, coef, pre, pre_rows);
     FVA_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     return FVA_OK;
 }

@@ -110,3 +110,4 @@ struct FvaProfileSpan {
 
 // diagnostic stamp buffer shared by the 8-phase kernels (set by fva_conv_debug_stamps)
 long long* fva_debug_stamps_ptr();
+int fva_debug_stamps_rows();

@@ -16,7 +16,7 @@
 
 namespace {
 
-enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_HEAD = 2, EPI_BNACT = 3 };   // BNACT: out = SiLU(acc * scale[n] + shift[n]) (+ addend)
+enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_HEAD = 2, EPI_BNACT = 3, EPI_BNB = 4 };   // BNACT: out = SiLU(acc * scale[n] + shift[n]) (+ addend); BNB: PLAIN + fused BatchNorm-backward statistics (IgemmParams::bnb_*)
 constexpr int MAX_TAPS = 10;
 
 struct IgemmParams {
@@ -95,6 +95,80 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
 __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
     const float u = (p.scale ? v * p.scale[n] : v) + p.shift[n];
     return p.act == 0 ? silu_f(u) : p.act == 1 ? fmaxf(u, 0.f) : u;
+}
+
+
+// The block's transposed bf16 tile (LDS, row pitch PITCH bytes) -> global memory, 16 bytes per thread and step.  A thread keeps
+// its 16-byte column chunk over all steps (NT % CPR == 0).  The global operands of a GROUP of steps -- the residual addend, and
+// for EPI_BNB the producer's y -- are fetched first, all in flight together, and consumed afterwards: issued one per step behind
+// the previous step's store, each load pays a full memory round trip (measured: +60 us on a 100 us dgrad launch).
+template <int EPI, int BM, int BN, int NT, int PITCH, typename OutPixel>
+__device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem, int tid, int m0, int n0, int mblk, OutPixel&& out_pixel,
+                                                const bf16x8* y_pre = nullptr) {
+    constexpr int CPR = BN / 8, ITERS = BM * CPR / NT, GROUP = 8, RSTEP = NT / CPR;
+    static_assert(NT % CPR == 0 && ITERS % GROUP == 0, "a thread keeps its column chunk; whole groups");
+    bf16_t* out = (bf16_t*)p.out;
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+    const bool col_ok = n < p.N;
+    const bool has_add = p.addend != nullptr;
+    BnbCoef kc;
+    float b1[8], b2[8];
+    if constexpr (EPI == EPI_BNB) {
+        bnb_load(p, n, kc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
+    }
+    for (int g = 0; g < ITERS / GROUP; ++g) {
+        int64_t oi[GROUP];
+        bool ok[GROUP];
+        bf16x8 ad[GROUP], yv[GROUP];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            const int m = m0 + r0 + (g * GROUP + j) * RSTEP;
+            ok[j] = col_ok && m < p.M;
+            oi[j] = ok[j] ? out_pixel(m) * p.out_pitch + n : 0;     // masked steps read element 0: no branch around a load
+        }
+        if (has_add) {
+#pragma unroll
+            for (int j = 0; j < GROUP; ++j) ad[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi[j]);
+        }
+        if constexpr (EPI == EPI_BNB) {
+            if (y_pre != nullptr) {       // fetched before the k loop (ITERS == GROUP): the launch's rounds of tiles run in lockstep,
+#pragma unroll                             // so a read issued in the epilogue is exposed, not hidden behind another block's MFMAs
+                for (int j = 0; j < GROUP; ++j) yv[j] = y_pre[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < GROUP; ++j) yv[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            const int row = r0 + (g * GROUP + j) * RSTEP;
+            bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
+            if (has_add) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[j][e]);
+            }
+            if (ok[j]) {
+                *(bf16x8*)(out + oi[j]) = v;
+                if constexpr (EPI == EPI_BNB) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yf = (float)yv[j][e];
+                        const float du = (float)v[e] * silu_grad(yf * kc.sc[e] + kc.sh[e]);
+                        b1[e] += du;
+                        b2[e] += du * (yf - kc.mu[e]);           // * rstd once, below
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_BNB) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b2[e] *= kc.rs[e];
+        bnb_finish<BN, NT, CPR>(p, (float*)smem, b1, b2, tid, mblk, n0);
+    }
 }
 
 template <typename T>
@@ -232,6 +306,32 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         for (int i = 0; i < B_ITERS; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(sB + (i * NW + w) * 1024), 16, 0, 0);
     };
+
+    // EPI_BNB (bf16): this thread's eight 16-byte pieces of the producer's y tile, in the store loop's (row, chunk) order
+    bf16x8 y_pre[8];
+    if constexpr (EPI == EPI_BNB && sizeof(T) == 2) {
+        constexpr int CPR = BN / 8, RSTEP = NT / CPR;
+        static_assert(BM * CPR / NT == 8, "the prefetch covers the whole store loop");
+        const int cc = tid % CPR, r0 = tid / CPR;
+        const int n = n0 + cc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + r0 + j * RSTEP;
+            int64_t oi = 0;
+            if (n < p.N && m < p.M) {
+                int64_t pixel = m;
+                if (!p.out_dense) {
+                    const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+                    const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+                    const uint32_t oy = fd_div(rem, p.div_ow);
+                    const uint32_t ox = rem - oy * (uint32_t)p.OW;
+                    pixel = (int64_t)b * p.out_img + (int64_t)(oy * p.osy + p.ooy) * p.out_row + (ox * p.osx + p.oox);
+                }
+                oi = pixel * p.out_pitch + n;
+            }
+            y_pre[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
+        }
+    }
 
     Acc<T> acc;
     if constexpr (sizeof(T) == 2) {
@@ -390,9 +490,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         float* out = (float*)p.out;
         int64_t pix_cache = -1;
         int m_cache = -1;
-        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
+        constexpr bool bnb = EPI == EPI_BNB;
         float b1[2] = {0.f, 0.f}, b2[2] = {0.f, 0.f}, ksc[2], ksh[2], kmu[2], krs[2];
-        if (bnb) {
+        if constexpr (bnb) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 int c = n0 + wcol0 + nt * 32 + (lane & 31);
@@ -412,8 +512,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 if constexpr (EPI == EPI_BNACT) v = bnact_f(p, v, n);
                 const float o = p.addend ? ((const float*)p.addend)[oi] + v : v;
                 out[oi] = o;
-                if constexpr (EPI == EPI_PLAIN) {
-                    if (bnb) {
+                if constexpr (EPI == EPI_BNB) {
+                    {
                         const float yv = ((const float*)p.bnb_y)[oi];
                         const float du = o * silu_grad(yv * ksc[nt] + ksh[nt]);
                         b1[nt] += du;
@@ -422,8 +522,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 }
             }
         });
-        if constexpr (EPI == EPI_PLAIN) {
-            if (bnb) {   // same wave-shuffle -> LDS -> plain-store scheme as the forward statistics
+        if constexpr (EPI == EPI_BNB) {
+            {   // same wave-shuffle -> LDS -> plain-store scheme as the forward statistics
                 float* red = (float*)smem;  // [2][BM/64][BN]
                 constexpr int WMc = BM / 64;
                 __syncthreads();
@@ -461,51 +561,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
         __syncthreads();
-        constexpr int CPR = BN / 8;  // 16-B chunks per row
-        constexpr int ITERS = BM * CPR / NT;
-        static_assert(NT % CPR == 0, "a thread keeps its column chunk over the store loop");
-        bf16_t* out = (bf16_t*)p.out;
-        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
-        BnbCoef kc;
-        float b1[8], b2[8];
-        if constexpr (EPI == EPI_PLAIN) {
-            if (bnb) {
-                bnb_load(p, n0 + (tid % CPR) * 8, kc);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int c = it * NT + tid;
-            const int row = c / CPR, cc = c - row * CPR;
-            const int m = m0 + row, n = n0 + cc * 8;
-            if (m < p.M && n < p.N) {
-                bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
-                const int64_t oi = out_pixel(m) * p.out_pitch + n;
-                if (p.addend) {
-                    const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
-                }
-                *(bf16x8*)(out + oi) = v;
-                if constexpr (EPI == EPI_PLAIN) {
-                    if (bnb) {
-                        const bf16x8 yv = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float yf = (float)yv[e];
-                            const float du = (float)v[e] * silu_grad(yf * kc.sc[e] + kc.sh[e]);
-                            b1[e] += du;
-                            b2[e] += du * (yf - kc.mu[e]) * kc.rs[e];
-                        }
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == EPI_PLAIN) {
-            if (bnb) bnb_finish<BN, NT, CPR>(p, (float*)smem, b1, b2, tid, mblk, n0);
-        }
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr);
     }
 }
 
@@ -553,7 +609,8 @@ struct StreamK {
     int32_t* flags;      // [grid] launch epoch of the slab + [grid] poll time-outs (diagnostic)
     int32_t epoch;
     int32_t tiles;
-    long long* stamps;   // diagnostic (fva_conv_debug_stamps): [grid][8], see the kernel's stamp()
+    long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8], see the kernel's stamp()
+    int stamp_rows;      // blocks beyond the caller's buffer do not stamp
 };
 
 template <int EPI, bool SK>
@@ -565,7 +622,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
     auto stamp = [&](int i) {   // per block: 4 wall-clock stamps, then the shader-clock cycle counter at the same points (ratio = the clock under load)
-        if (sk.stamps && tid == 0) {
+        if (sk.stamps && tid == 0 && (int)blockIdx.x < sk.stamp_rows) {
             sk.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
             sk.stamps[(int64_t)blockIdx.x * 8 + 4 + i] = clock64();
         }
@@ -865,49 +922,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
         });
         __syncthreads();
-        constexpr int CPR = BN / 8, ITERS = BM * CPR / NT;
-        bf16_t* out = (bf16_t*)p.out;
-        const bool bnb = EPI == EPI_PLAIN && p.bnb_part != nullptr;
-        BnbCoef kc;
-        float b1[8], b2[8];
-        if constexpr (EPI == EPI_PLAIN) {
-            if (bnb) {
-                bnb_load(p, n0 + (tid_e % CPR) * 8, kc);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
-            }
-        }
-#pragma unroll 4
-        for (int it = 0; it < ITERS; ++it) {
-            const int c = it * NT + tid_e;
-            const int row = c / CPR, cc = c - row * CPR;
-            const int m = m0 + row, n = n0 + cc * 8;
-            if (m < p.M && n < p.N) {
-                bf16x8 v = *(const bf16x8*)(smem + row * PITCH + cc * 16);
-                const int64_t oi = out_pixel(m) * p.out_pitch + n;
-                if (p.addend) {
-                    const bf16x8 old = *(const bf16x8*)((const bf16_t*)p.addend + oi);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
-                }
-                *(bf16x8*)(out + oi) = v;
-                if constexpr (EPI == EPI_PLAIN) {
-                    if (bnb) {
-                        const bf16x8 yv = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float yf = (float)yv[e];
-                            const float du = (float)v[e] * silu_grad(yf * kc.sc[e] + kc.sh[e]);
-                            b1[e] += du;
-                            b2[e] += du * (yf - kc.mu[e]) * kc.rs[e];
-                        }
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == EPI_PLAIN) {
-            if (bnb) bnb_finish<BN, NT, CPR>(p, (float*)smem, b1, b2, tid_e, mblk, n0);
-        }
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, m0, n0, mblk, out_pixel);
     }
     stamp(3);
 }
@@ -966,6 +981,7 @@ inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in
 }
 
 long long* g_stamps = nullptr;   // fva_conv_debug_stamps
+int g_stamp_rows = 0;
 
 template <int EPI>
 int launch_igemm8(const IgemmParams& p, hipStream_t s) {
@@ -980,6 +996,7 @@ int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     }
     StreamK sk{};
     sk.stamps = g_stamps;
+    sk.stamp_rows = g_stamp_rows;
     if (use_streamk(tiles, p.ktiles)) {
         sk.slabs = g_sk.slabs;
         sk.flags = g_sk.flags;
@@ -1196,10 +1213,13 @@ int fva_conv_set_workspace(void* ws, int64_t bytes) {
 
 }  // extern "C"
 long long* fva_debug_stamps_ptr() { return g_stamps; }
+int fva_debug_stamps_rows() { return g_stamp_rows; }
 extern "C" {
 
-int fva_conv_debug_stamps(void* stamps) {
+int fva_conv_debug_stamps(void* stamps, int32_t rows) {
+    if (stamps && rows < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_debug_stamps: rows must be >= 1");
     g_stamps = (long long*)stamps;
+    g_stamp_rows = stamps ? rows : 0;
     return FVA_OK;
 }
 
@@ -1440,7 +1460,7 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
         p.tap_w[nt] = k * k;
         finish_taps(p, nt, d->dtype);
         p.out_dense = 1;
-        return launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+        return f ? launch_igemm<EPI_BNB>(d->dtype, p, (hipStream_t)stream) : launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
     }
     const int JH = d->H / 2, JW = d->W / 2;
     if (dgrad_paired(k, s, d->Cin)) {
@@ -1472,7 +1492,7 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
             finish_taps(p, nt, d->dtype);
             if (p.halfrow) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad: paired stride-2 path needs Cout >= 64");
             p.ooy = py;
-            rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+            rc = f ? launch_igemm<EPI_BNB>(d->dtype, p, (hipStream_t)stream) : launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
             if (rc) return rc;
             p.bnb_row0 += dgrad_launch_rows(d, p.M, p.N, p.C, nt, in_pixels);
         }
@@ -1507,7 +1527,7 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
             finish_taps(p, nt, d->dtype);
             p.ooy = py;
             p.oox = px;
-            rc = launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
+            rc = f ? launch_igemm<EPI_BNB>(d->dtype, p, (hipStream_t)stream) : launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
             if (rc) return rc;
             p.bnb_row0 += dgrad_launch_rows(d, p.M, p.N, p.C, nt, in_pixels);
         }

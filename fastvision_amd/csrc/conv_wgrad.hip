@@ -40,6 +40,7 @@ struct WgradParams {
     int tpt, ngroups;  // taps packed side by side in one column tile (thin layers: C < tile), tap groups
     int x_pix_bytes;   // bytes between consecutive pixels of x; 0 = C * sizeof(T) (the stem reads overlapping 4-pixel windows)
     long long* stamps; // diagnostic (fva_conv_debug_stamps): per block 4 wall-clock + 4 cycle-counter values, 8-phase kernel only
+    int stamp_rows;    // capacity of the caller's buffer in blocks
 };
 
 // ds_read_b64_tr_b16 as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever an LDS-DMA
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
     auto stamp = [&](int i) {
-        if (p.stamps && tid == 0) {
+        if (p.stamps && tid == 0 && (int)blockIdx.x < p.stamp_rows) {
             p.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
             p.stamps[(int64_t)blockIdx.x * 8 + 4 + i] = clock64();
         }
@@ -661,6 +662,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
             attr_done = true;
         }
         p.stamps = fva_debug_stamps_ptr();
+        p.stamp_rows = fva_debug_stamps_rows();
         hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
     } else if (d->dtype == FVA_BF16)
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);

@@ -10,9 +10,23 @@
 
 namespace {
 
+// Device-resident step state (fva_adam_step_dev): the step count and the learning rate live in device memory, so that a
+// captured HIP graph of the whole training step replays with the right bias corrections and follows an LR schedule.
+// state[0] = step count (as a double: exact to 2^53), state[1] = lr / (1 - beta1^step), state[2] = sqrt(1 - beta2^step)
+__global__ void adam_tick_kernel(double* state, const float* __restrict__ lr, double beta1, double beta2) {
+    const double step = state[0] + 1.0;
+    state[0] = step;
+    state[1] = (double)*lr / (1.0 - pow(beta1, step));
+    state[2] = sqrt(1.0 - pow(beta2, step));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, int n,
                                                    float step_size, float bc2_sqrt, float beta1, float beta2, float eps, float wd,
-                                                   float gscale) {
+                                                   float gscale, const double* __restrict__ dev_state) {
+    if (dev_state) {
+        step_size = (float)dev_state[1];
+        bc2_sqrt = (float)dev_state[2];
+    }
     const int t = blockIdx.y;
     const int64_t size = sizes[t];
     float* p = (float*)ptrs[t];
@@ -47,7 +61,21 @@ extern "C" int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int3
     if (gx > 128) gx = 128;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, ptrs, sizes, n, step_size, bc2_sqrt, beta1,
-                       beta2, eps, weight_decay, grad_scale);
+                       beta2, eps, weight_decay, grad_scale, (const double*)nullptr);
+    FVA_LAUNCH_CHECK("adam_kernel");
+    return FVA_OK;
+}
+
+extern "C" int fva_adam_step_dev(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, const float* lr_dev, float beta1,
+                                 float beta2, float eps, float weight_decay, double* state_dev, float grad_scale, void* stream) {
+    if (!ptrs || !sizes || n < 1 || !lr_dev || !state_dev) return fva_fail(FVA_ERR_ARG, "fva_adam_step_dev: bad argument");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, lr_dev, (double)beta1, (double)beta2);
+    FVA_LAUNCH_CHECK("adam_tick_kernel");
+    int64_t gx = (max_size + 1023) / 1024;
+    if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, ptrs, sizes, n, 0.f, 1.f, beta1, beta2, eps,
+                       weight_decay, grad_scale, (const double*)state_dev);
     FVA_LAUNCH_CHECK("adam_kernel");
     return FVA_OK;
 }

@@ -17,7 +17,7 @@ from torch.utils.data import DataLoader, Dataset
 from ..detection.tools import xyxy2xywhn
 from ..pipeline_ops import PasteJob, pack_images, paste_batch, value_table
 
-__all__ = ['BaseDataset', 'DeviceLoader', 'create_dataloader', 'load_samples', 'letterbox_geometry']
+__all__ = ['BaseDataset', 'DeviceLoader', 'create_dataloader', 'load_samples', 'letterbox_geometry', 'show_dataset']
 
 IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
@@ -103,11 +103,13 @@ class BaseDataset(Dataset):
         return jobs
 
     def collate_host(self, batch):
-        """Worker-side half of collate_fn: one pinned byte buffer + the label table (no GPU work)."""
+        """Worker-side half of collate_fn: one byte buffer + the label table.  No GPU work and NO pinning here: this runs in
+        forked DataLoader workers, where pinning would need a GPU context per worker (and the pin would be lost anyway when the
+        tensor crosses the worker queue into shared memory).  The main process pins: DataLoader(pin_memory=True)."""
         rgbs, labels, flips = zip(*batch)
         for i, l in enumerate(labels):
             l[:, 0] = i
-        buf, offsets, shapes = pack_images(rgbs)
+        buf, offsets, shapes = pack_images(rgbs, pin=False)
         return buf, offsets, shapes, list(flips), torch.cat(labels, 0)
 
     def to_device(self, host_batch, device):
@@ -169,6 +171,26 @@ def create_dataloader(prefix, data_dir, batch_size, input_size, device, num_work
     samples = load_samples(data_dir, prefix, num_workers, cache, use_cache)
     dataset = BaseDataset(samples, input_size, max_det)
     device = torch.device(device) if not isinstance(device, torch.device) else device
-    loader = DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle, pin_memory=False, drop_last=drop_last,
-                        num_workers=num_workers if device.type != 'cpu' else 0, collate_fn=dataset.collate_host)
+    loader = DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle, pin_memory=bool(pin_memory) and device.type == 'cuda',
+                        drop_last=drop_last, num_workers=num_workers, collate_fn=dataset.collate_host)
     return DeviceLoader(loader, dataset, device)
+
+
+def show_dataset(prefix, data_dir, category_names, num_workers=0, cache='./cache', use_cache=False, out_dir=None, limit=None):
+    """The reference's label viewer (detection_dataloader.py:176-190) without a display: every sample's boxes are drawn into the
+    decoded image and written as a binary PPM under ``out_dir`` (default <cache>/show_<prefix>).  Returns the paths written."""
+    from ..detection.plot import draw_box_label
+    samples = load_samples(data_dir, prefix, num_workers, cache, use_cache)
+    out_dir = out_dir or os.path.join(cache, f'show_{prefix}')
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for img_path, labels in samples[:limit]:
+        img = np.ascontiguousarray(_decode_rgb(img_path))
+        for category_idx, xmin, ymin, xmax, ymax in labels:
+            draw_box_label(img, (xmin, ymin, xmax, ymax), text=str(category_names[int(category_idx)]), line_color=int(category_idx), bgr=False)
+        path = os.path.join(out_dir, os.path.splitext(os.path.basename(img_path))[0] + '.ppm')
+        with open(path, 'wb') as f:
+            f.write(f'P6 {img.shape[1]} {img.shape[0]} 255\n'.encode())
+            f.write(img.tobytes())
+        written.append(path)
+    return written

@@ -234,6 +234,52 @@ class _Saved:
     pass
 
 
+# ---- BatchNorm-backward statistics in the epilogue of the dgrad launch that produces dz --------------------------------------
+# The first pass of a block's BatchNorm backward (sum dU, sum dU * xhat over the batch, dU = dz * SiLU') needs dz complete.  When
+# the block's output z has ONE consumer and that consumer is one of our convolutions, the dgrad launch of the consumer writes
+# exactly dz (incl. the residual addend): it then also reads the block's y and leaves the partial sums (fva_conv_dgrad_bnstats),
+# and the block's own backward skips fva_bn_silu_bwd_reduce -- one read of dz and one launch less per layer (65 of the 72
+# BatchNorm layers of YOLOv3).  Forward tags every block output with the state of the block that produced it (z._fva_prod) and
+# counts the consumers it sees; backward trusts the sums only if the gradient it receives IS the consumer's buffer (pointer
+# identity; the consumer keeps a second reference to that buffer so that autograd cannot accumulate another gradient into it in
+# place): with a consumer this module does not know, or several, the block falls back to its own reduce pass.
+_BN_FUSE = [os.environ.get('FVA_BN_FUSE', '1') != '0']
+
+
+def set_bn_backward_fusion(on):
+    """Switch the fused BatchNorm-backward statistics on or off (default on; env FVA_BN_FUSE=0).  Returns the previous setting."""
+    prev = _BN_FUSE[0]
+    _BN_FUSE[0] = bool(on)
+    return prev
+
+
+def _note_consumer(x):
+    """A consumer of x that will hand back a gradient: called by every autograd node of this module in forward."""
+    src = getattr(x, '_fva_prod', None)
+    if src is not None:
+        src.consumers += 1
+    return src
+
+
+def _fuse_struct(src, part):
+    return _lib.BnBwdFuse(src.y.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr(), src.mean.data_ptr(), src.rstd.data_ptr(),
+                          part.data_ptr())
+
+
+def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
+    """fva_conv_dgrad, with the producer's BatchNorm-backward statistics in its epilogue when dx is that producer's whole dz."""
+    if (_BN_FUSE[0] and src is not None and src.consumers == 1 and src.training and src.dtype == dtype
+            and src.M == d.B * d.H * d.W and src.d.Cout == d.Cin and not torch.is_grad_enabled()):
+        rows = _lib.load().fva_conv_dgrad_stat_rows(C.byref(d))
+        if rows > 0:
+            part = torch.empty((_lib.load().fva_bn_partial_rows(rows) if rows > 2048 else rows, 2, d.Cin), dtype=torch.float32, device=dx.device)
+            fs = _fuse_struct(src, part)
+            _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
+            src.fused = (part, rows, dx.data_ptr(), dx)
+            return
+    _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
+
+
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
     """SiLU(BN(conv(x))) [+ residual].  x: logical [B,Cin,H,W]; x_ptr/x_pad describe its halo buffer.
     Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape."""
@@ -242,6 +288,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     lib = _lib.load()
     if not _conv_ws:
         ensure_conv_workspace(x.device)
+    x_src = _note_consumer(x) if need_ctx else None
     d = ConvDesc(_code(dtype), B, H, W, Cin, Cout, k, stride, x_pad, 1)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     M = B * OH * OW
@@ -288,6 +335,9 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         s.gamma, s.dtype, s.OH, s.OW, s.M, s.wshape = gamma, dtype, OH, OW, M, tuple(weight.shape)
         s.weight = weight
         s.training = training
+        s.x_src, s.consumers, s.fused = x_src, 0, None
+        if training:
+            z._fva_prod = s
     return z, s
 
 
@@ -403,10 +453,15 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     lib = _lib.load()
     d, dtype, dev = s.d, s.dtype, s.y.device
     Cout, code = d.Cout, _code(s.dtype)
-    nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
-    part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
-    _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-              _p(part), nb, s.M, Cout, _stream())
+    fused, s.fused = s.fused, None
+    if fused is not None and fused[2] == dz_ptr:
+        part, nb = fused[0], fused[1]              # the consumer's dgrad epilogue has already summed dU and dU * xhat
+    else:
+        nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
+        part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                  _p(part), nb, s.M, Cout, _stream())
+    del fused
     dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
     dbeta = torch.empty_like(dgamma)
     coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
@@ -421,7 +476,7 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
-        _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(s.wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
+        _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
     return dx, dw, dgamma, dbeta
 
 
@@ -602,6 +657,8 @@ class UpsampleConcatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, up, skip, up_first, dtype):
         require_gpu(up, 'UpSampling')
+        _note_consumer(up)            # their gradients come from upcat_bwd, not from a dgrad epilogue
+        _note_consumer(skip)
         ku, up_ptr, up_pad = to_halo(up, dtype, 0)
         ks, sk_ptr, sk_pad = to_halo(skip, dtype, 0)
         B, Cup, h, w = up.shape
@@ -635,6 +692,7 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dtype):
         require_gpu(x, 'head')
+        ctx.x_src = _note_consumer(x) if ctx.needs_input_grad[0] else None
         keep, x_ptr, x_pad = to_halo(x, dtype, 0)
         B, Cin, H, W = x.shape
         N = weight.shape[0]
@@ -671,7 +729,7 @@ class HeadFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((B, H, W, Cin), dtype=dtype, device=dev)
-            _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dxb), C.c_void_p(0), _stream())
+            _dgrad(d, dy, wd, dxb, None, ctx.x_src, dtype)
             dx = _grad_like(dxb, x_like)
         return dx, dwp[:N].contiguous(), dbias, None
 

@@ -105,8 +105,9 @@ int fva_conv_set_workspace(void* workspace, int64_t bytes);
 int64_t fva_conv_streamk_timeouts(void);
 /* Diagnostic: while set (non-NULL), every block of an 8-phase convolution launch writes eight values to stamps[block * 8 ..]:
  * wall_clock64 (100 MHz) at block entry, first k-tile ready, k-loop done and exit, then the shader-clock cycle counter at the
- * same four points (cycles / wall time = the shader clock under load).  The buffer must hold the largest grid. */
-int fva_conv_debug_stamps(void* stamps);
+ * same four points (cycles / wall time = the shader clock under load).  `rows` = capacity of the buffer in blocks (8 values
+ * each): blocks beyond it do not stamp.  NULL switches the stamps off. */
+int fva_conv_debug_stamps(void* stamps, int32_t rows);
 
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
@@ -124,6 +125,22 @@ int32_t fva_conv_stat_blocks(const fva_conv_desc* d);
 /* dx[B][H][W][Cin] (dense, dtype) = conv_transpose(dy, w) (+ addend).  dy is halo NHWC with border d->dy_pad.
  * addend (optional, dense like dx, may alias dx) is added in the epilogue: the residual-branch gradient sum. */
 int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream);
+
+/* The same data gradient with the FIRST pass of the BatchNorm backward of the layer that produced this convolution's input taken
+ * in its epilogue.  dx (incl. the addend) is dz of that producer block z = SiLU(BN(y)) (classfication/models/darknet53.py:28-31,
+ * 58-62: what autograd's native_batch_norm_backward + SiLU backward reduce over the batch): per row block and channel the
+ * epilogue adds up dU = dz * SiLU'(y * scale + shift) and dU * (y - mean) * rstd from the values it stores, reading y (dense
+ * [B*H*W][Cin], the producer's pre-BN output) once.  partial: [fva_conv_dgrad_stat_rows(d)][2][Cin] floats, plain stores, fixed
+ * order -- feed it to fva_bn_bwd_finalize in place of fva_bn_silu_bwd_reduce's table.  Valid only when dx IS the whole dz (the
+ * producer's output has no other consumer than this convolution and, through `addend`, the residual identity). */
+typedef struct {
+    const void* y;
+    const float *scale, *shift, *mean, *rstd;
+    float* partial;
+} fva_bn_bwd_fuse;
+int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
+                           const fva_bn_bwd_fuse* fuse, void* stream);
+int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d);
 
 /* dw (fp32, OIHW) (+)= sum_pixels dy x.  Deterministic: split-K partial tiles go to `workspace`
  * (fva_conv_wgrad_workspace() bytes) and are reduced in fixed order. */
@@ -193,8 +210,10 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
                            const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks,
                            int64_t M, int C, void* stream);
 int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
-/* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2. */
-int fva_bn_bwd_finalize(const float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
+/* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2.  partial: the table of
+ * fva_bn_silu_bwd_reduce (<= 2048 rows) or of fva_conv_dgrad_bnstats; a table of more than 2048 rows must have been allocated
+ * with fva_bn_partial_rows(nblocks) rows (it is folded in parallel first, into doubles kept behind the table). */
+int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
                         const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                         void* stream);
 /* Backward, pass 2: dy = gamma*rstd*(dU - dbeta/n - xhat*dgamma/n) written as halo buffer (border dy_pad). */
@@ -358,6 +377,12 @@ int fva_paste_resize_u8(const uint8_t* src, const fva_paste_job* jobs, const int
  * ---------------------------------------------------------------------------------------------- */
 int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same update with the step count and the learning rate in device memory, for a training step captured in a HIP graph
+ * (utils/fit.py:52-66 replayed as one launch): state_dev[3] doubles = {step count, lr / (1 - beta1^step), sqrt(1 - beta2^step)};
+ * the call first advances state_dev[0] by one and recomputes the two bias-corrected factors from *lr_dev (a device float the
+ * host may rewrite between replays: LR schedules), then updates the tensors.  Same arithmetic as fva_adam_step. */
+int fva_adam_step_dev(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, const float* lr_dev, float beta1,
+                      float beta2, float eps, float weight_decay, double* state_dev, float grad_scale, void* stream);
 
 /* ---- VGG blocks of the two-stage head's backbone (demos/faster_rcnn/models/vgg.py: Conv2d + bias -> ReLU,
  * MaxPool2d(2, 2); no BatchNorm) ---------------------------------------------------------------------------------------------

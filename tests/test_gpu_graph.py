@@ -1,0 +1,127 @@
+"""The training step captured in a HIP graph (graphs.GraphedTrainStep; the loop it replaces: utils/fit.py:52-66) against the same
+step issued eagerly: identical kernels in identical order on identical data, so losses, parameters, BatchNorm buffers and Adam
+moments must agree BIT FOR BIT after several steps -- including batches with fewer targets than the captured capacity (zero rows
+match no anchor) and a learning rate changed between replays (device-resident LR scalar)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def lib_model(seed=20220504):
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.synthetic import coco_anchors_px
+    torch.manual_seed(seed)
+    m = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+               in_channels=3, num_classes=80, training=True)
+    return m.to(DEV).train()
+
+
+def make(capturable=True):
+    from fastvision_amd import FusedAdam
+    from fastvision_amd.loss import Yolov3Loss
+    net = lib_model()
+    crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4, capturable=capturable)
+    return net, crit, opt
+
+
+def eager_step(net, crit, opt, images, tg):
+    pred = net(images)
+    opt.zero_grad()
+    loss = crit(pred, tg)
+    loss.backward()
+    opt.step()
+    return loss.detach().clone()
+
+
+def state_of(net, opt):
+    out = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for i, p in enumerate(net.parameters()):
+        out[f'm{i}'] = opt.state[p]['exp_avg'].clone()
+        out[f'v{i}'] = opt.state[p]['exp_avg_sq'].clone()
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_graphed_step_is_bit_identical_with_eager(dtype):
+    import fastvision_amd
+    from fastvision_amd.graphs import GraphedTrainStep
+    from fastvision_amd.synthetic import synthetic_batch
+    batches = [synthetic_batch(2, 128, seed=s) for s in (1234, 7, 99)]
+    cap = max(t.shape[0] for _, t in batches) + 5
+    lrs = [1e-4, 1e-4, 3e-5, 3e-5]
+    order = [0, 1, 2, 0]
+    with fastvision_amd.compute_dtype(dtype):
+        net, crit, opt = make()
+        want = []
+        for i, lr in zip(order, lrs):
+            opt.param_groups[0]['lr'] = lr
+            im, tg = batches[i]
+            want.append(eager_step(net, crit, opt, im.to(DEV), tg.to(DEV)))
+        want_state = state_of(net, opt)
+        torch.cuda.synchronize()
+
+        net2, crit2, opt2 = make()
+        im0, tg0 = batches[0]
+        step = GraphedTrainStep(net2, lambda p, t: crit2(p, t), opt2, im0.to(DEV), tg0.to(DEV), max_targets=cap)
+        got = []
+        for i, lr in zip(order, lrs):
+            opt2.param_groups[0]['lr'] = lr
+            im, tg = batches[i]
+            got.append(step(im.to(DEV), tg.to(DEV)).clone())
+        got_state = state_of(net2, opt2)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), (a, b)
+    for k in want_state:
+        assert torch.equal(got_state[k], want_state[k]), k
+    assert opt2._step_of(next(iter(net2.parameters()))) == 4
+    assert float(opt2._dev[0]['state'][0]) == 4.0
+    # the eval path after replays must see the updated parameters (packed-weight cache invalidated)
+    net.eval(); net2.eval()
+    with torch.no_grad(), fastvision_amd.compute_dtype(dtype):
+        a = net(batches[1][0].to(DEV), val=True)[1]
+        b = net2(batches[1][0].to(DEV), val=True)[1]
+    assert torch.equal(a, b)
+
+
+def test_device_resident_adam_matches_host_scalar_adam():
+    """fva_adam_step_dev (step count / LR in device memory) against fva_adam_step (host scalars): the bias corrections are computed
+    by pow() on the device instead of the host's libm, so allow one ulp of the step size (1e-6 relative on the update)."""
+    import fastvision_amd
+    from fastvision_amd.synthetic import synthetic_batch
+    im, tg = synthetic_batch(2, 64)
+    im, tg = im.to(DEV), tg.to(DEV)
+    res = []
+    with fastvision_amd.compute_dtype(torch.float32):
+        for cap in (False, True):
+            net, crit, opt = make(capturable=cap)
+            p0 = [p.detach().clone() for p in net.parameters()]
+            for _ in range(3):
+                eager_step(net, crit, opt, im, tg)
+            res.append([(p.detach() - q) for p, q in zip(net.parameters(), p0)])
+    worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item() for a, b in zip(*res))
+    print('largest relative difference of the 3-step parameter update', worst)
+    assert worst < 1e-5
+
+
+def test_graphed_step_refuses_what_it_cannot_capture():
+    from fastvision_amd import FusedAdam
+    from fastvision_amd.graphs import GraphedTrainStep
+    from fastvision_amd.loss import Yolov3Loss
+    from fastvision_amd.synthetic import synthetic_batch
+    net = lib_model()
+    crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+    im, tg = synthetic_batch(2, 64)
+    with pytest.raises(RuntimeError):
+        GraphedTrainStep(net, crit, FusedAdam(net.parameters(), lr=1e-4), im.to(DEV), tg.to(DEV))     # host-scalar optimizer
+    opt = FusedAdam(net.parameters(), lr=1e-4, capturable=True)
+    step = GraphedTrainStep(net, crit, opt, im.to(DEV), tg.to(DEV), max_targets=tg.shape[0])
+    with pytest.raises(ValueError):
+        step(im.to(DEV), torch.cat([tg, tg]).to(DEV))                                                 # more targets than captured

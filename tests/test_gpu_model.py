@@ -258,12 +258,59 @@ def test_loss_curve_100_steps_fp32_vs_reference(gold_lib, gold_demo, surface):
     if surface == 'demo':
         assert rel.max() < 1e-3, f'demo: max rel deviation {rel.max()} at step {rel.argmax()}'
     else:
-        # The library loss trajectory is chaotic at the 1e-2 level: the CPU reference re-run in the build container
-        # with 1 or 3 threads instead of 8 (only the reduction order changes) deviates from its own golden curve by
-        # 1.6e-2 / 1.4e-2 (max over the 100 steps; 7e-5 / 1.6e-5 at step 10) -- see DESIGN.md "Parity".  So the 1e-3
-        # bar is enforced on the first 10 steps and the whole curve must stay inside the reference's own spread.
+        # The library loss trajectory is chaotic at the 1e-2 level IN THE REFERENCE ITSELF: its objectness target is the
+        # non-detached IoU of the prediction (loss/yolov3_loss.py:60-61).  oracle/make_golden.py lib_curves re-ran the reference's
+        # 100 steps with 1, 3 and 8 intra-op threads (only the order of the fp32 reductions changes): g6_curve_t{1,3,8}.  The GPU
+        # curve must hold 1e-3 on the first 10 steps and afterwards stay inside 1.5 x the reference's own spread (its largest
+        # deviation from itself over the 100 steps: where along the curve two runs part company is itself chaotic).
+        spread = np.max([np.abs(gold_lib[f'g6_curve_t{t}'] - gold) / np.abs(gold) for t in (1, 3, 8)], axis=0)
+        print(f'reference spread over thread counts: max {spread.max():.2e} at step {spread.argmax()} (first 10 steps {spread[:10].max():.2e}); '
+              f'GPU max deviation / reference spread = {rel.max() / spread.max():.2f}')
         assert rel[:10].max() < 1e-3, f'lib: first-10 rel deviation {rel[:10].max()}'
-        assert rel.max() < 3e-2, f'lib: max rel deviation {rel.max()} at step {rel.argmax()}'
+        assert rel.max() <= 1.5 * spread.max(), f'lib: max rel deviation {rel.max()} at step {rel.argmax()}, reference spread {spread.max()}'
+
+
+def test_loss_curve_100_steps_bf16_reported(gold_lib, gold_demo):
+    """The bench dtype (bf16 storage, fp32 accumulate / statistics / loss / master weights) on the same 100 steps, both surfaces:
+    observed deviation from the reference's fp32 curve is printed (first run: library 5.4e-3 over the first 10 steps, 1.8e-2 at
+    most, 4.4e-3 on average; demo 3.6e-2 at step 4 -- its loss jumps 18 -> 12 -> 13.4 over the first steps -- and 2.1e-3 on
+    average).  Bars: library 2e-2 over the first 10 steps and 2e-2 + 3 x the reference's own spread overall; demo 6e-2 overall
+    and 1e-2 on average."""
+    import fastvision_amd
+    from fastvision_amd import FusedAdam
+    images, tg = synthetic_batch(2, 128)
+    images, tg = images.to(DEV), tg.to(DEV)
+    for surface in ('lib', 'demo'):
+        with fastvision_amd.compute_dtype(torch.bfloat16):
+            if surface == 'lib':
+                net, crit, gold = lib_model(), lib_loss(), gold_lib['g6_curve']
+                step_loss = lambda pred: crit(pred, tg)
+            else:
+                from fastvision_amd.demos.yolov3_u.models import YoloV3
+                from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+                torch.manual_seed(20220504)
+                net = YoloV3(anchors=coco_anchors_feature()).to(DEV).train()
+                cl, gold = ComputeLoss(), gold_demo['g6_curve']
+                step_loss = lambda pred: _silently(cl, pred, tg, net)
+            opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+            curve = []
+            for _ in range(100):
+                pred = net(images)
+                opt.zero_grad()
+                loss = step_loss(pred)
+                loss.backward()
+                opt.step()
+                curve.append(loss.detach().reshape(1))
+        curve = torch.cat(curve).cpu().numpy()
+        rel = np.abs(curve - gold) / np.abs(gold)
+        print(f'bf16 {surface} curve: first {curve[:3]} last {curve[-3:]} (reference {gold[:3]} .. {gold[-3:]}); max rel dev {rel.max():.2e} at '
+              f'step {rel.argmax()}, first-10 max {rel[:10].max():.2e}, mean {rel.mean():.2e}')
+        assert np.all(np.isfinite(curve)) and curve[-1] < curve[0]
+        if surface == 'lib':
+            spread = np.max([np.abs(gold_lib[f'g6_curve_t{t}'] - gold) / np.abs(gold) for t in (1, 3, 8)], axis=0)
+            assert rel[:10].max() < 2e-2 and rel.max() <= 2e-2 + 3 * spread.max()
+        else:
+            assert rel.max() < 6e-2 and rel.mean() < 1e-2
 
 
 # ------------------------------------------------------------------------------------------------ bf16 path (the bench dtype)

@@ -39,10 +39,10 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
             stamps.zero_()
-            _lib.call('fva_conv_debug_stamps', ops._p(stamps))
+            _lib.call('fva_conv_debug_stamps', ops._p(stamps), 4096)
             fwd()
             torch.cuda.synchronize()
-            _lib.call('fva_conv_debug_stamps', C.c_void_p(0))
+            _lib.call('fva_conv_debug_stamps', C.c_void_p(0), 0)
             raw = stamps.cpu().numpy().reshape(-1, 8)
             raw = raw[raw[:, 3] > 0]
             s, cyc = raw[:, :4], raw[:, 4:]
@@ -83,10 +83,10 @@ def wgrad():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         stamps.zero_()
-        _lib.call('fva_conv_debug_stamps', ops._p(stamps))
+        _lib.call('fva_conv_debug_stamps', ops._p(stamps), 4096)
         run()
         torch.cuda.synchronize()
-        _lib.call('fva_conv_debug_stamps', C.c_void_p(0))
+        _lib.call('fva_conv_debug_stamps', C.c_void_p(0), 0)
         raw = stamps.cpu().numpy().reshape(-1, 8)
         raw = raw[raw[:, 3] > 0]
         s, cyc = raw[:, :4], raw[:, 4:]
