@@ -1,0 +1,5 @@
+"""Shim: `inference` of the reference's demos/yolov3_u resolves to `fastvision_amd.demos.yolov3_u.inference` (the same module object)."""
+import importlib
+import sys
+
+sys.modules[__name__] = importlib.import_module('fastvision_amd.demos.yolov3_u.inference')

@@ -1,0 +1,5 @@
+"""Shim: `utils.map` of the reference's demos/yolov3_u resolves to `fastvision_amd.demos.yolov3_u.utils.map` (the same module object)."""
+import importlib
+import sys
+
+sys.modules[__name__] = importlib.import_module('fastvision_amd.demos.yolov3_u.utils.map')

@@ -106,6 +106,7 @@ PROTOTYPES = {
     'fva_yolov3_loss': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _P, _L, _P]),
     'fva_yolov3_loss_workspace': (_L, [_I, _H, _I]),
     'fva_yolov3_loss_dp': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _I, _P, _P, _L, _P]),
+    'fva_bce_loss': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
     'fva_demo_loss': (_I, [_P, _I, _H, _I, _P, _P, _L, _P]),
     'fva_demo_loss_workspace': (_L, [_I, _H, _I]),
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),

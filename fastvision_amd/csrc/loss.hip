@@ -590,6 +590,47 @@ __global__ void iou_batch_kernel(int kind, int mode, int variant, const float* a
         out[i] = iou_any(kind, mode, variant, a + (i / M) * w, b + (i % M) * w, eps, true).v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone BiCrossEntropyLoss (loss/classification_loss.py:36-65): per element
+//   l = -t log(p + 1e-8) - (1 - t) log(1 - p + 1e-8),  p = y or sigmoid(y),  t = one-hot(label) or the dense target,
+// times an optional per-element weight; block partial sums in fixed order, and dl/dy for the backward.
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ y, const int64_t* __restrict__ label,
+                                                  const float* __restrict__ dense_t, const float* __restrict__ w, int64_t w_numel,
+                                                  int64_t numel, int C, int already_sigmoid, float* __restrict__ partial,
+                                                  float* __restrict__ grad) {
+    __shared__ float wsum[4];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / C;
+        const int k = (int)(i - row * C);
+        const float t = label ? ((int64_t)k == label[row] ? 1.f : 0.f) : dense_t[i];
+        const float v = y[i];
+        const float p = already_sigmoid ? v : sigm(v);
+        const float wi = w ? (w_numel == 1 ? w[0] : w[i]) : 1.f;
+        acc += wi * (-t * logf(p + BCE_EPS) - (1.f - t) * logf(1.f - p + BCE_EPS));
+        if (grad) {
+            const float dldp = -t / (p + BCE_EPS) + (1.f - t) / (1.f - p + BCE_EPS);
+            grad[i] = wi * dldp * (already_sigmoid ? 1.f : p * (1.f - p));
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void bce_final_kernel(const float* __restrict__ partial, int nblocks, double denom, float* out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0.0;
+        for (int i = 0; i < 256; ++i) s += red[i];
+        out[0] = (float)(s / denom);
+    }
+}
+
 inline int64_t align256(int64_t x) { return (x + 255) & ~255ll; }
 struct Carver {
     char* p;
@@ -749,6 +790,22 @@ int fva_demo_loss(const float* targets, int32_t T, const fva_head_level* levels,
             FVA_LAUNCH_CHECK("demo_conf_kernel");
         }
     }
+    return FVA_OK;
+}
+
+int fva_bce_loss(const float* y, const int64_t* label, const float* dense_target, const float* weights, int64_t weights_numel,
+                 int64_t numel, int32_t C, int32_t already_sigmoid, int32_t mean, float* loss_out, float* grad, float* workspace,
+                 void* stream) {
+    if (!y || (!label && !dense_target) || !loss_out || !workspace || numel < 1 || C < 1 || numel % C)
+        return fva_fail(FVA_ERR_ARG, "fva_bce_loss: bad argument");
+    if (weights && weights_numel != 1 && weights_numel != numel) return fva_fail(FVA_ERR_ARG, "fva_bce_loss: weights must have 1 or numel entries");
+    const int blocks = (int)((numel + 255) / 256 < CONF_BLOCKS ? (numel + 255) / 256 : CONF_BLOCKS);
+    hipLaunchKernelGGL(bce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, label, dense_target, weights, weights_numel, numel, C,
+                       already_sigmoid, workspace, grad);
+    FVA_LAUNCH_CHECK("bce_kernel");
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, mean ? (double)numel : 1.0,
+                       loss_out);
+    FVA_LAUNCH_CHECK("bce_final_kernel");
     return FVA_OK;
 }
 

@@ -14,7 +14,7 @@ import torch
 from ...pipeline_ops import PasteJob, canvas_sources, pack_images, paste_batch, paste_batch_u8, value_table
 from .utils.box import xyxy2xywhn
 
-__all__ = ['DeviceAugmenter', 'resize_by_max_shape']
+__all__ = ['DeviceAugmenter', 'resize_by_max_shape', 'HostImageBatch', 'BaseDataset', 'create_dataset']
 
 
 def resize_by_max_shape(h, w, max_size):
@@ -54,11 +54,24 @@ class DeviceAugmenter:
             l[:, 0] = i
         return images, torch.cat(labels, 0).to(self.device, non_blocking=True)
 
-    def val_batch(self, samples):
+    def val_labels(self, samples):
+        """the label half of val_batch alone (host arithmetic; used by the DataLoader-side collate of BaseDataset)"""
+        S, labels = self.input_size, []
+        for img, xyxy, cat in samples:
+            h, w = img.shape[:2]
+            ratio, rh, rw = resize_by_max_shape(h, w, S)
+            top, left = int((S - rh) // 2), int((S - rw) // 2)
+            lab = np.asarray(xyxy, dtype=np.float32) * ratio
+            lab[:, [1, 3]] = lab[:, [1, 3]] + top
+            lab[:, [0, 2]] = lab[:, [0, 2]] + left
+            labels.append(self._labels(lab, cat))
+        return labels
+
+    def val_batch(self, samples, packed=None):
         """samples: list of (rgb uint8 [h,w,3], xyxy float32 [n,4], category [n]).  ResizeByMax(input_size) -> Padding(128) ->
         / 255 (data_gen.py:42-92,356-360) for the whole batch in one launch."""
         S = self.input_size
-        buf, offsets, shapes = pack_images([s[0] for s in samples])
+        buf, offsets, shapes = packed if packed is not None else pack_images([s[0] for s in samples])
         jobs, labels = [], []
         for i, ((h, w), (_, xyxy, cat)) in enumerate(zip(shapes, samples)):
             ratio, rh, rw = resize_by_max_shape(h, w, S)
@@ -71,13 +84,39 @@ class DeviceAugmenter:
         images = paste_batch(buf, offsets, shapes, jobs, len(samples), S, S, self.fill_value, self.table, self.device)
         return self._collate(images, labels)
 
-    def train_batch(self, groups):
+    def train_labels(self, groups):
+        """the label half of train_batch alone (host arithmetic, same expressions in the same order)"""
+        S, labels = self.input_size, []
+        cx = cy = S // 2
+        for g in groups:
+            boxes, cats = [], []
+            for idx, (img, xyxy, cat, hf, vf) in enumerate(g):
+                h, w = img.shape[:2]
+                ratio, rh, rw = resize_by_max_shape(h, w, S)
+                lab = np.asarray(xyxy, dtype=np.float32) * ratio
+                if hf:
+                    lab = _hflip_boxes(lab, rw)
+                if vf:
+                    lab = _vflip_boxes(lab, rh)
+                ratio2, th, tw = resize_by_max_shape(rh, rw, S // 2)
+                x0 = cx - tw if idx in (0, 2) else cx
+                y0 = cy - th if idx in (0, 1) else cy
+                lab = lab * ratio2
+                lab[:, [0, 2]] = lab[:, [0, 2]] + x0
+                lab[:, [1, 3]] = lab[:, [1, 3]] + y0
+                boxes.append(lab)
+                cats.append(np.asarray(cat))
+            xyxy = np.clip(np.concatenate(boxes, axis=0), 0, S - 1)
+            labels.append(self._labels(xyxy, np.concatenate(cats, axis=0).reshape(-1)))
+        return labels
+
+    def train_batch(self, groups, packed=None):
         """groups: per output image a list of FOUR (rgb, xyxy, category, hflip, vflip) -- the sample and its three random
         companions (data_gen.py:338-345).  Pass 1 (uint8): ResizeByMax(input_size) + flips of all 4*B images; pass 2:
         Mosaic01 (each tile resized again to input_size // 2 on its longer side, the four meet at the centre) + / 255."""
         S = self.input_size
         flat = [t for g in groups for t in g]
-        buf, offsets, shapes = pack_images([t[0] for t in flat])
+        buf, offsets, shapes = packed if packed is not None else pack_images([t[0] for t in flat])
         jobs1, mid_shapes, mid_boxes = [], [], []
         for i, ((h, w), (_, xyxy, cat, hf, vf)) in enumerate(zip(shapes, flat)):
             ratio, rh, rw = resize_by_max_shape(h, w, S)
@@ -112,3 +151,106 @@ class DeviceAugmenter:
         images = paste_batch(mid.view(-1), m_off, m_shapes, jobs2, len(groups), S, S, self.fill_value, self.table, self.device,
                              pitches=m_pitch)
         return self._collate(images, labels)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's dataset surface (data_gen.py:247-394: BaseDataset, collate_fn, create_dataset), so that its train.py builds its
+# loaders unchanged:  DataLoader(dataset=create_dataset(dir, size, mode), collate_fn=dataset.collate_fn, pin_memory=True,
+# num_workers=N)  ->  for images, target in loader: images = images.cuda(non_blocking=True) ...
+# Workers only decode files and draw the random numbers (no GPU context in a forked worker); collate_fn packs the decoded bytes
+# and computes the labels (host arithmetic of DeviceAugmenter's plan); the image batch it returns is a ``HostImageBatch`` whose
+# ``.cuda()`` / ``.to(device)`` uploads the bytes and runs the resize / flip / pad / mosaic / "/255" kernels -- the train loop's
+# own ``images.cuda(non_blocking=True)`` is what launches them.
+class HostImageBatch:
+    """Decoded images of one batch (packed uint8 bytes) + the geometric plan; becomes the [B,3,S,S] float tensor on the device."""
+
+    def __init__(self, mode, input_size, fill_value, samples):
+        self.mode, self.input_size, self.fill_value, self.samples = mode, int(input_size), int(fill_value), samples
+        self.buf, self.offsets, self.shapes = pack_images([s[0] for s in (samples if mode != 'train' else [t for g in samples for t in g])], pin=False)
+
+    def __len__(self):
+        return len(self.samples)
+
+    def size(self, dim=None):
+        shape = (len(self.samples), 3, self.input_size, self.input_size)
+        return shape if dim is None else shape[dim]
+
+    shape = property(lambda self: self.size())
+
+    def pin_memory(self):
+        self.buf = self.buf.pin_memory()
+        return self
+
+    def to(self, device, non_blocking=False):
+        aug = DeviceAugmenter(self.input_size, device, self.fill_value)
+        packed = (self.buf, self.offsets, self.shapes)
+        if self.mode == 'train':
+            return aug.train_batch(self.samples, packed=packed)[0]
+        return aug.val_batch(self.samples, packed=packed)[0]
+
+    def cuda(self, device=None, non_blocking=False):
+        return self.to(torch.device('cuda', torch.cuda.current_device()) if device is None else device, non_blocking)
+
+
+class BaseDataset(torch.utils.data.Dataset):
+    """samples: array of (image path, label path); label files hold ``class xmin ymin xmax ymax`` per line (data_gen.py:269-282)."""
+
+    def __init__(self, samples, input_size, mode, fill_value=128):
+        self.samples, self.input_size, self.mode, self.fill_value = samples, int(input_size), mode, fill_value
+        self._planner = DeviceAugmenter(self.input_size, 'cpu', fill_value)       # label arithmetic only
+
+    def __len__(self):
+        return len(self.samples)
+
+    def load_image(self, img_path):
+        from ...datasets.detection_dataloader import _decode_rgb
+        return _decode_rgb(img_path)
+
+    def load_label(self, label_path):
+        rows = []
+        with open(label_path, 'r') as f:
+            for line in f:
+                if line.strip():
+                    rows.append(line.split())
+        return np.array(rows, dtype=np.float32).reshape([-1, 5])
+
+    def _one(self, img_path, label_path):
+        import random
+        image, label = self.load_image(img_path), self.load_label(label_path)
+        train = self.mode == 'train'
+        hf = train and random.random() <= 0.5
+        vf = train and random.random() <= 0.5
+        return image, label[:, 1:], label[:, 0], hf, vf
+
+    def __getitem__(self, idx):
+        import random
+        first = self._one(self.samples[idx][0], self.samples[idx][1])
+        if self.mode != 'train':
+            return first[:3]
+        group = [first]
+        for _ in range(3):
+            r = random.choice(self.samples)
+            group.append(self._one(r[0], r[1]))
+        return group
+
+    def collate_fn(self, batch):
+        """-> (HostImageBatch, targets [T,6] float32 on the host): the reference's (images, labels) pair (data_gen.py:366-371)"""
+        images = HostImageBatch(self.mode, self.input_size, self.fill_value, list(batch))
+        plan = self._planner
+        labels = plan.train_labels(batch) if self.mode == 'train' else plan.val_labels(batch)
+        for i, l in enumerate(labels):
+            l[:, 0] = i
+        return images, torch.cat(labels, 0)
+
+
+def create_dataset(base_dir, input_size, mode):
+    """<base_dir>/images/* with <base_dir>/labels/<name>.txt (data_gen.py:373-394); sample order shuffled with numpy's generator"""
+    import os
+    label_dir, image_dir = os.path.join(base_dir, 'labels'), os.path.join(base_dir, 'images')
+    samples = []
+    for img_name in sorted(os.listdir(image_dir)):
+        samples.append((os.path.join(image_dir, img_name), os.path.join(label_dir, f"{img_name.split('.')[0]}.txt")))
+    samples = np.array(samples).reshape([-1, 2])
+    np.random.shuffle(samples)
+    print(f'total samples: {len(samples)}')
+    return BaseDataset(samples, input_size, mode)

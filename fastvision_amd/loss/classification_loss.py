@@ -31,20 +31,49 @@ class CrossEntropyLoss(nn.Module):
         return torch.mean(loss) if self.reduction == 'mean' else torch.sum(loss)
 
 
+class _BceFn(torch.autograd.Function):
+    """fva_bce_loss: value and dl/dy in one launch (+ a one-block finish); backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, y, label, dense, weights, C, already_sigmoid, mean):
+        import ctypes as Ct
+        from .. import _lib
+        from ..ops import _p, _stream, require_gpu
+        require_gpu(y, 'BiCrossEntropyLoss')
+        yf = y.detach().float().contiguous().view(-1)
+        numel = yf.numel()
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(yf) if need else None
+        out = torch.empty(1, dtype=torch.float32, device=y.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=y.device)
+        w = weights.detach().float().contiguous().view(-1) if weights is not None else None
+        if w is not None and w.numel() not in (1, numel):
+            w = w.expand(numel // w.numel(), w.numel()).contiguous().view(-1) if numel % w.numel() == 0 else w
+        lab = label.detach().long().contiguous().view(-1) if label is not None else None
+        den = dense.detach().float().contiguous().view(-1) if dense is not None else None
+        _lib.call('fva_bce_loss', _p(yf), _p(lab), _p(den), _p(w), w.numel() if w is not None else 0, numel, C, 1 if already_sigmoid else 0,
+                  1 if mean else 0, _p(out), _p(grad), _p(ws), _stream())
+        ctx.grad, ctx.shape, ctx.dtype, ctx.scale = grad, y.shape, y.dtype, (1.0 / numel if mean else 1.0)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = (ctx.grad * (gout * ctx.scale)).view(ctx.shape)
+        return (g if g.dtype == ctx.dtype else g.to(ctx.dtype)), None, None, None, None, None, None
+
+
 class BiCrossEntropyLoss(nn.Module):
+    """loss/classification_loss.py:36-65 on the device: ``forward(y_pre, y_true, already_sigmoid=False, weights=None)``.  A last
+    dimension > 1 means class scores with integer labels (one-hot targets); a last dimension of 1 a dense float target.  1e-8 sits
+    inside both logarithms; ``mean`` divides the summed element losses by the element count.  Device tensors only (the reference's
+    CPU use of this class, config 1's plumbing, goes through CrossEntropyLoss above)."""
+
     def __init__(self, reduction='mean'):
         super().__init__()
         self.reduction = reduction
 
     def forward(self, y_pre, y_true, already_sigmoid=False, weights=None):
-        if y_pre.size(-1) > 1:
-            target = one_hot(y_true, y_pre.size(-1)).float().view(-1, 1)
-        else:
-            target = y_true.float().view(-1, 1)
-        p = y_pre.view(-1, 1)
-        if not already_sigmoid:
-            p = p.sigmoid()
-        loss = torch.sum(-target * torch.log(p + 1e-8) - (1 - target) * torch.log(1 - p + 1e-8), dim=1)
-        if weights is not None:
-            loss = loss * weights
-        return torch.sum(loss) / p.numel() if self.reduction == 'mean' else torch.sum(loss)
+        C = y_pre.size(-1)
+        if C > 1:
+            return _BceFn.apply(y_pre, y_true, None, weights, C, already_sigmoid, self.reduction == 'mean')
+        return _BceFn.apply(y_pre, None, y_true, weights, 1, already_sigmoid, self.reduction == 'mean')

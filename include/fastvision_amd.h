@@ -284,6 +284,15 @@ int fva_yolov3_loss_dp(const float* targets, int32_t T, const fva_head_level* le
                        float ratio_box, float ratio_conf, float ratio_cls, const int32_t* norm_counts, int32_t norm_batch,
                        float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Stand-alone BiCrossEntropyLoss (loss/classification_loss.py:36-65) forward + dl/dy.  y [numel] fp32 logits (or probabilities:
+ * already_sigmoid) seen as rows of C classes; target = one-hot of label[numel / C] (int64) or, label == NULL, the dense float
+ * target [numel]; weights: NULL, one value, or numel values.  loss_out[1] = sum of the weighted element losses (/ numel when
+ * mean); grad (optional, [numel]) = d(sum of weighted element losses)/dy, NOT divided by numel.  workspace: 1024 floats.
+ * Deterministic (fixed-order partial sums). */
+int fva_bce_loss(const float* y, const int64_t* label, const float* dense_target, const float* weights, int64_t weights_numel,
+                 int64_t numel, int32_t C, int32_t already_sigmoid, int32_t mean, float* loss_out, float* grad, float* workspace,
+                 void* stream);
+
 /* Demo loss (demos/yolov3_u/utils/lossv3.py:18-119): best-anchor assignment, BCE/MSE/BCE terms, IoU>0.5
  * ignore mask, masked objectness BCE.  level.anchor_* are FEATURE-scale here and level.stride is unused.
  * loss_out[5] = {total, xy, wh, cls, conf} (unweighted parts, as the reference prints them). */

@@ -609,3 +609,153 @@ def test_bf16_step_same_with_and_without_8phase_kernels(tmp_path):
     assert abs(both['loss'][0] - base['loss'][0]) <= 1e-4 * abs(base['loss'][0])
     rel = np.array([abs(both[k][0] - base[k][0]) / max(base[k][0], 1e-12) for k in base.files if k.startswith('norm/')])
     assert np.median(rel) < 5e-3 and rel.max() < 5e-2, (np.median(rel), rel.max())
+
+
+# ------------------------------------------------------------------------------------------------ a-9 stand-alone BCE class
+def test_bicrossentropy_class_vs_reference(gold_lib):
+    """loss/classification_loss.py:36-65 on the device kernel fva_bce_loss, against the reference's own outputs
+    (g2_bce_*: probabilities with integer labels / mean, logits / sum) and against torch autograd for the gradient, the dense-
+    target form (last dimension 1, as Yolov3Loss's objectness term calls it) and weights."""
+    from fastvision_amd.loss import BiCrossEntropyLoss
+    p, lab = T(gold_lib['g2_bce_p']).to(DEV), T(gold_lib['g2_bce_lab']).to(DEV)
+    got = BiCrossEntropyLoss('mean')(p, lab, already_sigmoid=True)
+    np.testing.assert_allclose(got.detach().cpu().numpy().reshape(1), gold_lib['g2_bce_mean'], rtol=1e-5)
+    logits = (p * 4 - 2).clone().requires_grad_(True)
+    got = BiCrossEntropyLoss('sum')(logits, lab)
+    np.testing.assert_allclose(got.detach().cpu().numpy().reshape(1), gold_lib['g2_bce_logits_sum'], rtol=1e-5)
+    got.backward()
+    ref = (p * 4 - 2).detach().cpu().clone().requires_grad_(True)
+    tgt = torch.zeros(12, 5).scatter_(1, lab.cpu().view(-1, 1), 1.0).view(-1, 1)
+    s = ref.view(-1, 1).sigmoid()
+    (-tgt * torch.log(s + 1e-8) - (1 - tgt) * torch.log(1 - s + 1e-8)).sum().backward()
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), ref.grad.numpy(), rtol=1e-4, atol=1e-6)
+    # dense target + per-element weights, mean
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(50, 1, generator=g)
+    t = torch.rand(50, 1, generator=g)
+    w = torch.rand(50, generator=g)
+    yd = y.to(DEV).requires_grad_(True)
+    got = BiCrossEntropyLoss('mean')(yd, t.to(DEV), weights=w.to(DEV))
+    got.backward()
+    yr = y.clone().requires_grad_(True)
+    sr = yr.sigmoid()
+    want = ((-t * torch.log(sr + 1e-8) - (1 - t) * torch.log(1 - sr + 1e-8)).sum(1) * w).sum() / 50
+    want.backward()
+    np.testing.assert_allclose(got.item(), want.item(), rtol=1e-5)
+    np.testing.assert_allclose(yd.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        BiCrossEntropyLoss()(p.cpu(), lab.cpu())
+
+
+# ------------------------------------------------------------------------------------------------ DataParallel semantics, N ranks
+def _dp_sum_worker(rank, world, port, out):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      FVA_DIST_BACKEND='gloo')
+    import torch.distributed as dist
+    import fastvision_amd
+    from fastvision_amd import parallel
+    parallel.init_from_env()
+    with fastvision_amd.compute_dtype(torch.float32):
+        net, crit = lib_model(seed=20220504), lib_loss()
+        crit.data_parallel()                                             # job-wide match counts and batch in the loss kernel
+        red = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20, average=False)
+        images, tg = synthetic_batch(4, 64, seed=77)                     # global batch of 4, two images per rank
+        pred = net(images[rank * 2:(rank + 1) * 2].to(DEV))
+        loss = crit(pred, parallel.shard_targets(tg, rank, 2).to(DEV))
+        loss.backward()
+        red.finish()
+        share = loss.detach().clone()
+        dist.all_reduce(share)                                           # the shares add up to the gathered-batch loss
+        g = {k: p.grad.detach().cpu().clone() for k, p in list(net.named_parameters())[::23]}
+    out[rank] = (g, float(share), float(loss))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_reproduces_the_reference_dataparallel_step():
+    """Two ranks (one GPU, gloo), each with its own two images: the loss kernel normalises its per-match means by the match counts
+    of the WHOLE job and multiplies by the job's batch (fva_yolov3_loss_dp), gradients are SUMMED.  Reference semantics
+    (demos/yolov3_u/train.py:85 nn.DataParallel + loss/yolov3_loss.py:69-71): every replica runs forward on its shard (per-GPU
+    BatchNorm statistics), the outputs are gathered and ONE loss is evaluated on the 4-image batch.  Emulated in-process: two
+    shard forwards, concatenated heads, one loss; parameter gradients must agree to fp32 rounding."""
+    import socket
+    import torch.multiprocessing as mp
+    import fastvision_amd
+    from fastvision_amd import ops, parallel
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.start_processes(_dp_sum_worker, args=(2, port, out), nprocs=2, join=True, start_method='spawn')
+    (g0, total0, share0), (g1, total1, share1) = out[0], out[1]
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    prev = ops.set_wgrad_side_stream(False)      # one weight receives two gradient contributions inside ONE backward pass here
+    try:
+        with fastvision_amd.compute_dtype(torch.float32):
+            net, crit = lib_model(seed=20220504), lib_loss()
+            images, tg = synthetic_batch(4, 64, seed=77)
+            preds = [net(images[r * 2:(r + 1) * 2].to(DEV)) for r in range(2)]
+            gathered = [torch.cat([preds[0][l], preds[1][l]], 0) for l in range(3)]
+            loss = crit(gathered, tg.to(DEV))
+            loss.backward()
+            want = {k: p.grad.detach().cpu() for k, p in list(net.named_parameters())[::23]}
+    finally:
+        ops.set_wgrad_side_stream(prev)
+    assert abs(total0 - float(loss)) <= 1e-5 * abs(float(loss)) and total0 == total1 and share0 != share1
+    for k in g0:
+        err = ((g0[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-12)).item()
+        assert err < 1e-4, f'{k}: {err}'
+
+
+def _nccl_worker(rank, world, port, out):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    import fastvision_amd
+    from fastvision_amd import FusedAdam, parallel
+    parallel.init_from_env('nccl')
+    dev = f'cuda:{rank}'
+    torch.manual_seed(20220504 + rank)
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.loss import Yolov3Loss
+    net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+                 in_channels=3, num_classes=80, training=True).to(dev).train()
+    parallel.broadcast_parameters(net)
+    crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5).data_parallel()
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
+    red = parallel.GradientReducer(net.parameters(), average=False, bucket_dtype=torch.bfloat16)
+    images, tg = synthetic_batch(4, 128, rank=rank)
+    launched = 0
+    for _ in range(2):
+        opt.zero_grad()
+        loss = crit(net(images.to(dev)), tg.to(dev))
+        loss.backward()
+        launched = red.next_launch
+        red.finish()
+        opt.step()
+    torch.cuda.synchronize()
+    out[rank] = ({k: p.detach().cpu().clone() for k, p in list(net.named_parameters())[::17]}, launched, len(red.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL refuses two ranks on one device')
+def test_two_ranks_over_rccl():
+    """The N > 1 path on its real backend: two ranks on two GPUs, RCCL all-reduce of bf16 gradient buckets launched from the
+    autograd hooks on the side stream, job-wide loss normalisation, FusedAdam -- both ranks must hold bit-identical parameters
+    after two steps, and all but the last two buckets must have been launched before backward ended."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.start_processes(_nccl_worker, args=(2, port, out), nprocs=2, join=True, start_method='spawn')
+    (w0, l0, nb), (w1, l1, _) = out[0], out[1]
+    assert l0 == l1 and l0 >= nb - 2
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

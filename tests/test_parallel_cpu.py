@@ -94,3 +94,72 @@ def test_shard_targets_rebases_image_index():
     s = parallel.shard_targets(t, rank=1, per_rank_batch=2)
     assert s[:, 0].tolist() == [0.0, 1.0] and s[:, 1].tolist() == [3.0, 4.0]
     assert parallel.shard_targets(t, 0, 2)[:, 1].tolist() == [1.0, 2.0]
+
+
+def _sum_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from fastvision_amd import parallel
+    parallel.init_from_env('gloo')
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    parallel.broadcast_parameters(net)
+    b = 3                                                            # images per rank
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(world * b, 16, generator=g)
+    res = {}
+    for tag, kw in (('sum', dict(average=False)), ('sum_bf16', dict(average=False, bucket_dtype=torch.bfloat16)), ('avg', dict(average=True))):
+        red = parallel.GradientReducer(net.parameters(), bucket_bytes=700, **kw)
+        net.zero_grad()
+        mine = x[rank * b:(rank + 1) * b]
+        (net(mine).square().mean() * b).backward()                   # the library loss shape: (mean over the rank's batch) * batch
+        red.finish()
+        res[tag] = [p.grad.clone() for p in net.parameters()]
+        red.remove()
+        for p in net.parameters():
+            p.grad = None
+    out[rank] = (res, [p.detach().clone() for p in net.parameters()], x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sum_reduction_reproduces_the_loss_on_the_gathered_batch():
+    """Yolov3Loss is (means) * batch (loss/yolov3_loss.py:69-71); under the reference's nn.DataParallel it is evaluated once on the
+    batch gathered from all replicas.  With one process per GPU the ranks' "* b" losses must be SUMMED (GradientReducer(average=
+    False)): then the reduced gradient equals the single-process gradient of (mean over all N*b samples) * (N*b).  AVG gives 1/N of
+    it.  The bf16 wire format carries the same sum to bf16 precision."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res, params, x = out[0]
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), params):
+            p.copy_(v)
+    (net(x).square().mean() * x.shape[0]).backward()                 # the gathered batch, as DataParallel's loss sees it
+    for got, p in zip(res['sum'], net.parameters()):
+        assert torch.allclose(got, p.grad, rtol=1e-5, atol=1e-6)
+    for got, p in zip(res['sum_bf16'], net.parameters()):
+        assert got.dtype == torch.float32 and torch.allclose(got, p.grad, rtol=2e-2, atol=2e-2 * p.grad.abs().max().item())
+    for got, p in zip(res['avg'], net.parameters()):
+        assert torch.allclose(got, p.grad / 2, rtol=1e-5, atol=1e-6)
+    for a, b in zip(out[0][0]['sum_bf16'], out[1][0]['sum_bf16']):
+        assert torch.equal(a, b)                                       # identical on every rank
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` is ONE command (the reference wraps itself in nn.DataParallel, demos/yolov3_u/train.py:85): the
+    parent spawns the ranks before it touches a GPU.  Here on the CPU: --dry-run (gloo, the model's real 61.9 M parameters, stand-in
+    gradients through the bucketed reducer) must print one JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['dry_run'] is True and d['reduced_gradients_ok'] is True and d['n_params'] == 61949149
+    assert d['config']['parallelism'] == 'dp2' and d['value'] is None
