@@ -46,6 +46,10 @@ class BnBwdFuse(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('y', 'scale', 'shift', 'mean', 'rstd', 'partial')]
 
 
+class ColourJob(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('h', 'w', 'clahe', 'hsv', 'blur')] + [('perm', C.c_int32 * 3)]
+
+
 class MatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('count', 'b', 'gx', 'gy', 'a', 'cls', 'xywh', 'anc')]
 
@@ -115,6 +119,9 @@ PROTOTYPES = {
     'fva_adam_step_dev': (_I, [_P, _P, _I, _L, _P, _F, _F, _F, _F, _P, _F, _P]),
     'fva_paste_resize_normalize': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'fva_paste_resize_u8': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    'fva_colour_workspace': (_L, [_I]),
+    'fva_colour_clahe_hsv': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+    'fva_colour_blur_shuffle_normalize': (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     'fva_yolo_decode': (_I, [_H, _I, _I, C.POINTER(Letterbox), _P, _L, _P]),
     'fva_nms_candidates_workspace': (_L, [_I, _I]),
     'fva_nms_candidates': (_I, [_P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P]),
@@ -133,7 +140,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

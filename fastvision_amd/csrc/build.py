@@ -17,10 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 LIB = os.path.join(HERE, 'libfastvision_amd.so')
 SOURCES = ['errors.hip', 'conv_igemm.hip', 'conv_wgrad.hip', 'bn_act.hip', 'stem.hip', 'head.hip', 'loss.hip',
-           'optim.hip', 'detect.hip', 'pipeline.hip', 'roi.hip', 'vgg.hip']
+           'optim.hip', 'detect.hip', 'pipeline.hip', 'colour.hip', 'roi.hip', 'vgg.hip']
 # -ffp-contract=off: the matcher must reproduce the reference's fp32 op order bit for bit (no FMA fusion)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
-PER_FILE = {'loss.hip': ['-ffp-contract=off'], 'detect.hip': ['-ffp-contract=off'], 'roi.hip': ['-ffp-contract=off']}
+PER_FILE = {'colour.hip': ['-ffp-contract=off'], 'loss.hip': ['-ffp-contract=off'], 'detect.hip': ['-ffp-contract=off'], 'roi.hip': ['-ffp-contract=off']}
 
 
 def _newer(src, obj):

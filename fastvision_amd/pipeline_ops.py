@@ -93,3 +93,55 @@ def paste_batch_u8(src, offsets, shapes, jobs, n_canvas, height, width, fill, de
     out = torch.empty(n_canvas, height, width, 3, dtype=torch.uint8, device=device)
     _lib.call('fva_paste_resize_u8', _p(src), _p(tab), _p(start), n_canvas, height, width, int(fill), _p(out), _stream())
     return out
+
+
+# ---- colour / blur stage of the demo's training path (csrc/colour.hip) --------------------------------------------------------
+def _colour_jobs(regions, clahe, hsv, blur, perms, device):
+    n = len(regions)
+    arr = (_lib.ColourJob * n)()
+    for i, (h, w) in enumerate(regions):
+        a = arr[i]
+        a.h, a.w = int(h), int(w)
+        a.clahe, a.hsv, a.blur = int(bool(clahe[i])), int(bool(hsv[i])), int(blur[i])
+        for c in range(3):
+            a.perm[c] = int(perms[i][c])
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device, non_blocking=True)
+
+
+def hsv_tables(gains):
+    """The three byte tables of HueSaturationValue for gains r (float64 [3], data_gen.py:125-131): (x * r0) % 180, clip(x * r1, 0, 255),
+    clip(x * r2, 0, 255), truncated to uint8 -- computed on the host exactly as the reference computes them."""
+    x = np.arange(0, 256, dtype=np.float64)
+    g = np.asarray(gains, dtype=np.float64)
+    return np.stack([((x * g[0]) % 180).astype(np.uint8), np.clip(x * g[1], 0, 255).astype(np.uint8), np.clip(x * g[2], 0, 255).astype(np.uint8)])
+
+
+def clahe_hsv_(canvases, regions, clahe, hsv_luts):
+    """In place on uint8 canvases [n,H,W,3] (device): per image [HistEqualize: CLAHE on the luma] then [HueSaturationValue tables].
+    regions: (h, w) of every image's valid top-left area; clahe: flags; hsv_luts: per image None or uint8 [3,256]."""
+    n, H, W, _ = canvases.shape
+    if not any(clahe) and not any(l is not None for l in hsv_luts):
+        return canvases
+    dev = canvases.device
+    jobs = _colour_jobs(regions, clahe, [l is not None for l in hsv_luts], [0] * n, [(0, 1, 2)] * n, dev)
+    tabs = np.zeros((n, 3, 256), dtype=np.uint8)
+    for i, l in enumerate(hsv_luts):
+        if l is not None:
+            tabs[i] = l
+    luts = torch.from_numpy(tabs).to(dev, non_blocking=True)
+    ws = torch.empty(_lib.load().fva_colour_workspace(n), dtype=torch.uint8, device=dev)
+    _lib.call('fva_colour_clahe_hsv', _p(canvases), n, H, W, _p(jobs), max(int(r[0]) for r in regions), max(int(r[1]) for r in regions),
+              _p(luts), _p(ws), _stream())
+    return canvases
+
+
+def blur_shuffle_normalize(canvases, blur, perms, table):
+    """uint8 canvases [n,H,W,3] (device) -> float32 [n,3,H,W]: per image a 3x3 blur (0 none, 1 box, 2 median, 3 Gaussian), the channel
+    permutation (output c = input perms[i][c]) and the byte -> value table (x / 255)."""
+    n, H, W, _ = canvases.shape
+    dev = canvases.device
+    jobs = _colour_jobs([(H, W)] * n, [0] * n, [0] * n, blur, perms, dev)
+    lut = torch.from_numpy(table).to(dev, non_blocking=True) if isinstance(table, np.ndarray) else table
+    out = torch.empty(n, 3, H, W, dtype=torch.float32, device=dev)
+    _lib.call('fva_colour_blur_shuffle_normalize', _p(canvases), n, H, W, _p(jobs), _p(lut), _p(out), _stream())
+    return out

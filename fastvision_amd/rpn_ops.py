@@ -74,6 +74,9 @@ def rpn_sample(labels_image, positives_per_image=128, negatives_per_image=128, p
     n_neg = min(neg.numel(), max(negatives_per_image, positives_per_image + negatives_per_image - n_pos))
     perm_pos = torch.randperm(pos.numel(), device=labels_image.device) if perm_pos is None else perm_pos
     perm_neg = torch.randperm(neg.numel(), device=labels_image.device) if perm_neg is None else perm_neg
+    if perm_pos.numel() > pos.numel() or perm_neg.numel() > neg.numel():        # a longer permutation would index out of range on the device
+        raise ValueError(f'rpn_sample: permutations of {perm_pos.numel()} / {perm_neg.numel()} entries for {pos.numel()} positives / '
+                         f'{neg.numel()} negatives')
     return pos[perm_pos[:n_pos]], neg[perm_neg[:n_neg]]
 
 

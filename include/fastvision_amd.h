@@ -379,6 +379,26 @@ int fva_paste_resize_normalize(const uint8_t* src, const fva_paste_job* jobs, co
 int fva_paste_resize_u8(const uint8_t* src, const fva_paste_job* jobs, const int32_t* job_start, int32_t B, int32_t H,
                         int32_t W, int32_t fill, uint8_t* out, void* stream);
 
+/* Colour / blur extras of the demo's training image path (demos/yolov3_u/data_gen.py:26-33,120-146), on uint8 canvases
+ * [B][H][W][3] resident in device memory (the output of fva_paste_resize_u8).  One job per canvas image. */
+typedef struct {
+    int32_t h, w;        /* valid region of the canvas image, anchored at its top-left corner */
+    int32_t clahe;       /* 1: HistEqualize -- CLAHE (clip limit 2.0, 8 x 8 tiles) on the luma of OpenCV's 8-bit YUV */
+    int32_t hsv;         /* 1: HueSaturationValue -- the image's three 256-byte tables applied in OpenCV's 8-bit HSV (H < 180) */
+    int32_t blur;        /* fva_colour_blur_shuffle_normalize: 0 none, 1 cv2.blur 3x3, 2 cv2.medianBlur 3, 3 cv2.GaussianBlur 3x3 sigma 0 */
+    int32_t perm[3];     /* fva_colour_blur_shuffle_normalize: output channel c is input channel perm[c] (ChannelShuffle) */
+} fva_colour_job;
+/* In place on the valid region of every canvas: [CLAHE] then [HSV tables].  jobs: DEVICE array [B]; hsv_luts: DEVICE bytes
+ * [B][3][256] (hue, saturation, value tables; read only for jobs with hsv = 1); max_h / max_w: largest valid region;
+ * workspace: fva_colour_workspace(B) bytes (the 64 tile tables of every image). */
+int64_t fva_colour_workspace(int32_t B);
+int fva_colour_clahe_hsv(uint8_t* canvases, int32_t B, int32_t H, int32_t W, const fva_colour_job* jobs, int32_t max_h, int32_t max_w,
+                         const uint8_t* hsv_luts, uint8_t* workspace, void* stream);
+/* canvases [B][H][W][3] uint8 -> out [B][3][H][W] fp32: per image a 3x3 blur (or none) over the whole canvas, the channel
+ * permutation, then lut[channel][value] (x / 255 as the reference computes it: ToTensorV2 + `/ 255.`). */
+int fva_colour_blur_shuffle_normalize(const uint8_t* canvases, int32_t B, int32_t H, int32_t W, const fva_colour_job* jobs,
+                                      const float* lut, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (demos/yolov3_u/train.py:68), multi-tensor.
  * ptrs: device array [4][n] of {param, grad, exp_avg, exp_avg_sq} fp32 pointers; sizes: device int64[n].
