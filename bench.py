@@ -174,12 +174,19 @@ def main():
     ap.add_argument('--surface', default='lib', choices=['lib', 'demo'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='also print per-layer-shape conv timings to stderr')
+    ap.add_argument('--model', default='yolov3', choices=['yolov3', 'faster_rcnn'],
+                    help='faster_rcnn: the train step of the reference\'s Faster R-CNN demo at BASELINE config 5 (4x3x800x1333, one GPU)')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: launcher + rendezvous + gradient reduction over gloo only')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
         sys.exit(spawn_ranks(args.gpus))
     if args.dry_run:
         sys.exit(dry_run(args))
+    if args.model == 'faster_rcnn':
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_faster
+        bench_faster.main(steps=min(args.steps, 20), warmup=args.warmup, cpu_baseline=not args.no_cpu_baseline)
+        return
 
     import torch.distributed as dist
     import fastvision_amd
@@ -321,9 +328,25 @@ def main():
         side_use = 'on' in cand and side_check['on'] <= side_check['off']
         gstep = cand['on' if side_use else 'off']
         cand.clear()
-        fva_ops.set_wgrad_side_stream(side_use)
-        step = gstep
-        graph_info = {'capture_s': round(time.perf_counter() - t_cap, 2)}
+        graph_ms = side_check['on' if side_use else 'off']
+        graph_info = {'capture_s': round(time.perf_counter() - t_cap, 2), 'replay_ms_per_step': graph_ms}
+        # A captured step has no host work left, but on ROCm 7.2 a graph with a second branch (the weight gradients on the side
+        # stream) replays far slower than the same work issued eagerly on two streams, so its replays are single-stream.  When the
+        # host keeps up, the eager two-stream step can therefore still be the faster one: time it too and use the winner.
+        eager = fva_ops.autotune_wgrad_side_stream(eager_step, fence, steps=3)
+        eager_use = eager.pop('use')
+        eager_ms = eager['on' if eager_use else 'off']
+        graph_info['eager_ms_per_step'] = eager
+        if os.environ.get('FVA_BENCH_MODE', 'auto') == 'graph' or (os.environ.get('FVA_BENCH_MODE', 'auto') == 'auto' and graph_ms <= eager_ms):
+            fva_ops.set_wgrad_side_stream(side_use)
+            step = gstep
+            graph_info['used'] = 'graph'
+        else:
+            use_graph, side_use, step = False, eager_use, eager_step
+            fva_ops.set_wgrad_side_stream(side_use)
+            del gstep
+            graph_info['used'] = 'eager'
+            side_check = dict(eager, graph_off=side_check.get('off'), graph_on=side_check.get('on'))
     else:
         side_check = fva_ops.autotune_wgrad_side_stream(step, fence, steps=3)
         side_use = side_check.pop('use')
@@ -476,7 +499,7 @@ def main():
                             'timed region, with the weight gradients on the launch stream (in the timed region they run on a '
                             'low-priority side stream beside the rest of backward, and only the roofline class is bracketed)',
             'wgrad_side_stream': bool(side_use), 'side_stream_check_ms_per_step': side_check,
-            'hip_graph': graph_info if use_graph else False,
+            'hip_graph': graph_info if graph_info is not None else False,
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
             'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
             'step_ms': [round(step_marks[i].elapsed_time(step_marks[i + 1]), 2) for i in range(args.steps)],

@@ -111,6 +111,10 @@ PROTOTYPES = {
     'fva_yolov3_loss_workspace': (_L, [_I, _H, _I]),
     'fva_yolov3_loss_dp': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _I, _P, _P, _L, _P]),
     'fva_bce_loss': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
+    'fva_row_loss': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    'fva_smooth_l1': (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    'fva_rows_relu_bwd_rows': (_I, [_I]),
+    'fva_rows_relu_bwd': (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     'fva_demo_loss': (_I, [_P, _I, _H, _I, _P, _P, _L, _P]),
     'fva_demo_loss_workspace': (_L, [_I, _H, _I]),
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),
@@ -140,7 +144,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

@@ -631,6 +631,57 @@ __global__ __launch_bounds__(256) void bce_final_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Losses of the two-stage head (demos/faster_rcnn/models/rpn.py:8-64,303-312, fast.py:173-201): over rows of logits with integer
+// labels -- mode 0: F.cross_entropy(reduction='mean'); mode 1: the RPN's FocalLoss, -(1 - p_t)^gamma log p_t, mean -- and
+// F.smooth_l1_loss(reduction='mean') (beta = 1).  Value and gradient in one launch, a one-block fixed-order finish.
+__global__ __launch_bounds__(256) void row_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int R, int C,
+                                                       int mode, float gamma, float* __restrict__ row_loss, float* __restrict__ grad) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float* z = logits + (int64_t)r * C;
+    const int y = (int)labels[r];
+    float m = z[0];
+    for (int k = 1; k < C; ++k) m = fmaxf(m, z[k]);
+    float den = 0.f;
+    for (int k = 0; k < C; ++k) den += expf(z[k] - m);
+    const float logp = (z[y] - m) - logf(den), p = expf(logp);
+    float loss, dldlogp;          // d loss / d log p_t: grad_k = dldlogp * (delta_ky - softmax_k)
+    if (mode == 0) {
+        loss = -logp;
+        dldlogp = -1.f;
+    } else {
+        const float q = 1.f - p;
+        const float qg = powf(q, gamma);
+        loss = -qg * logp;
+        // d/dp [-(1-p)^g log p] * p, with d p / d z_k = p (delta - s_k)
+        dldlogp = (gamma * powf(q, gamma - 1.f) * logp - qg / p) * p;
+    }
+    row_loss[r] = loss;
+    if (grad) {
+        const float inv = 1.f / (float)R;
+        for (int k = 0; k < C; ++k) {
+            const float sk = expf(z[k] - m) / den;
+            grad[(int64_t)r * C + k] = dldlogp * ((k == y ? 1.f : 0.f) - sk) * inv;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ partial,
+                                                        float* __restrict__ grad) {
+    __shared__ float wsum[4];
+    float acc = 0.f;
+    const float inv = 1.f / (float)n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i], ad = fabsf(d);
+        acc += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        if (grad) grad[i] = (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * inv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 inline int64_t align256(int64_t x) { return (x + 255) & ~255ll; }
 struct Carver {
     char* p;
@@ -805,6 +856,26 @@ int fva_bce_loss(const float* y, const int64_t* label, const float* dense_target
     FVA_LAUNCH_CHECK("bce_kernel");
     hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, mean ? (double)numel : 1.0,
                        loss_out);
+    FVA_LAUNCH_CHECK("bce_final_kernel");
+    return FVA_OK;
+}
+
+int fva_row_loss(const float* logits, const int64_t* labels, int32_t R, int32_t C, int32_t mode, float gamma, float* loss_out, float* grad,
+                 float* workspace, void* stream) {
+    if (!logits || !labels || !loss_out || !workspace || R < 1 || C < 1 || mode < 0 || mode > 1) return fva_fail(FVA_ERR_ARG, "fva_row_loss: bad argument");
+    hipLaunchKernelGGL(row_loss_kernel, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, logits, labels, R, C, mode, gamma, workspace, grad);
+    FVA_LAUNCH_CHECK("row_loss_kernel");
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, R, (double)R, loss_out);
+    FVA_LAUNCH_CHECK("bce_final_kernel");
+    return FVA_OK;
+}
+
+int fva_smooth_l1(const float* pred, const float* target, int64_t n, float* loss_out, float* grad, float* workspace, void* stream) {
+    if (!pred || !target || !loss_out || !workspace || n < 1) return fva_fail(FVA_ERR_ARG, "fva_smooth_l1: bad argument");
+    const int blocks = (int)((n + 255) / 256 < CONF_BLOCKS ? (n + 255) / 256 : CONF_BLOCKS);
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, n, workspace, grad);
+    FVA_LAUNCH_CHECK("smooth_l1_kernel");
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, (double)n, loss_out);
     FVA_LAUNCH_CHECK("bce_final_kernel");
     return FVA_OK;
 }

@@ -134,6 +134,37 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
     }
 }
 
+// Fully connected layers of the Fast head (demos/faster_rcnn/models/vgg.py classifier: Linear -> ReLU): dY = dZ * (Z > 0) over rows
+// [R][C] (any C that is a multiple of the 16-byte chunk) and, per block of 32 rows, the column sums of dY (= partial dbias).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_relu_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z, T* __restrict__ dy,
+                                                            float* __restrict__ partial, int R, int C, int relu) {
+    constexpr int EPC = Vec16<T>::N;
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc * EPC >= C) return;
+    const int r0 = blockIdx.y * 32, r1 = min(R, r0 + 32);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const int64_t off = (int64_t)r * C + cc * EPC;
+        const Vec16<T> g = *(const Vec16<T>*)(dz + off);
+        Vec16<T> o;
+        if (relu) {
+            const Vec16<T> zz = *(const Vec16<T>*)(z + off);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.set(e, zz.get(e) > 0.f ? g.get(e) : 0.f);
+        } else {
+            o = g;
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += o.get(e);
+        *(Vec16<T>*)(dy + off) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) partial[(int64_t)blockIdx.y * C + cc * EPC + e] = acc[e];
+}
+
 int chan_ok(const char* who, int dtype, int C, bool need_pow2) {
     if (dtype != FVA_F32 && dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "%s: bad dtype", who);
     const int epc = dtype == FVA_BF16 ? 8 : 4;
@@ -164,6 +195,23 @@ int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void*
         hipLaunchKernelGGL(bias_relu_bwd_kernel<float>, grid, dim3(256), smem, s, (const float*)dz, (const float*)z, z_pad, (float*)dy, dy_pad, partial,
                            B, H, W, C);
     FVA_LAUNCH_CHECK("bias_relu_bwd_kernel");
+    return FVA_OK;
+}
+
+int32_t fva_rows_relu_bwd_rows(int32_t R) { return cdiv(R, 32); }
+
+int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, float* partial, int32_t R, int32_t C, int32_t relu, void* stream) {
+    int rc = chan_ok("fva_rows_relu_bwd", dtype, C, false);
+    if (rc) return rc;
+    if (!dz || (relu && !z) || !dy || !partial || R <= 0) return fva_fail(FVA_ERR_ARG, "fva_rows_relu_bwd: bad argument");
+    const int epc = dtype == FVA_BF16 ? 8 : 4;
+    const dim3 grid(cdiv(C / epc, 256), cdiv(R, 32));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL(rows_relu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dy, partial, R, C, relu);
+    else
+        hipLaunchKernelGGL(rows_relu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, (const float*)z, (float*)dy, partial, R, C, relu);
+    FVA_LAUNCH_CHECK("rows_relu_bwd_kernel");
     return FVA_OK;
 }
 

@@ -7,14 +7,16 @@ same constructor arguments, parameter names and return values).
                regression against targets normalised by std (0.1, 0.1, 0.2, 0.2)
     inference: per image RoIAlign of its proposals, heads, decode, arg-max class, background dropped -> [n, 6] = xywh, class, score
 
-The fully connected layers (25088 -> 4096 -> 4096 -> classes / boxes) are plain library GEMMs (torch.nn.Linear = rocBLAS); the
-few hundred rows of loss arithmetic are torch ops on the device.  ``perms``: optional per-image (perm_pos, perm_neg) instead of
-``torch.randperm``.
+The fully connected layers (25088 -> 4096 -> 4096 -> classes / boxes) run on the library's implicit-GEMM kernels as 1x1 convolutions
+over the RoI rows (fc_ops.linear_relu: bias + ReLU epilogue; fc_ops.linear: the biased head convolution), cross-entropy and smooth-L1
+with their gradients in one launch each (fva_row_loss / fva_smooth_l1).  ``perms``: optional per-image (perm_pos, perm_neg) instead
+of ``torch.randperm``.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ....fc_ops import cross_entropy_mean, linear, linear_relu, smooth_l1_mean
 from ....roi_ops import roi_align
 from ....rpn_ops import fast_select_samples
 
@@ -44,8 +46,23 @@ class Fast(nn.Module):
     def _heads(self, feature_backbone, rois_xyxy):
         """rois [K, 5] = image, x1, y1, x2, y2 -> (class logits [K, classes + 1], box regression [K, 4 or (classes + 1) * 4])"""
         pooled = roi_align(feature_backbone, rois_xyxy, output_size=(self.fast_roi_pool, self.fast_roi_pool))
-        hidden = self.module_after_roi(torch.flatten(pooled, 1))
-        return self.classifier(hidden), self.regressor(hidden)
+        hidden = torch.flatten(pooled, 1)
+        if hidden.size(0) == 0:
+            return hidden.new_zeros((0, self.classifier.out_features)), hidden.new_zeros((0, self.regressor.out_features))
+        layers = list(self.module_after_roi)
+        i = 0
+        while i < len(layers):                       # Linear + ReLU pairs of the VGG classifier fuse into one launch; Dropout stays
+            layer = layers[i]
+            if isinstance(layer, nn.Linear) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                hidden = linear_relu(hidden, layer)
+                i += 2
+            elif isinstance(layer, nn.Linear):
+                hidden = linear(hidden, layer)
+                i += 1
+            else:
+                hidden = layer(hidden)
+                i += 1
+        return linear(hidden, self.classifier), linear(hidden, self.regressor)
 
     @staticmethod
     def _pick_class_box(box, cls_idx):
@@ -55,10 +72,10 @@ class Fast(nn.Module):
         if positive_cls.size(0) == 0:
             return torch.zeros(1).to(positive_cls), torch.zeros(1).to(positive_box)
         std = torch.tensor(BOX_STD).to(target_txtytwth)
-        loss_box = F.smooth_l1_loss(positive_box, target_txtytwth / std, reduction='mean')
+        loss_box = smooth_l1_mean(positive_box, target_txtytwth / std)
         logits = torch.cat([positive_cls, negative_cls], dim=0)
         labels = torch.cat([target_cls.view(-1) + 1, torch.zeros(negative_cls.size(0)).to(target_cls)], dim=0).long()
-        return F.cross_entropy(logits, labels, reduction='mean'), loss_box
+        return cross_entropy_mean(logits, labels), loss_box
 
     def forward(self, feature_backbone, proposals, targets=None, perms=None):
         bs, c, h, w = feature_backbone.shape

@@ -28,6 +28,9 @@ class FocalLoss(nn.Module):
         self.gamma, self.class_num, self.size_average = gamma, class_num, size_average
 
     def forward(self, inputs, targets):
+        if inputs.is_cuda and self.size_average and bool((self.alpha == 1).all()):
+            from ....fc_ops import focal_mean
+            return focal_mean(inputs, targets, float(self.gamma))              # value + gradient in one launch (fva_row_loss)
         p_t = torch.softmax(inputs, dim=1).gather(1, targets.view(-1, 1))
         loss = -self.alpha.to(inputs.device)[targets.view(-1)].view(-1, 1) * torch.pow(1 - p_t, self.gamma) * p_t.log()
         return loss.mean() if self.size_average else loss.sum()
@@ -80,7 +83,8 @@ class RPN(nn.Module):
             box_tg.append(torch.stack([(boxes[:, 0] - a[:, 0]) / a[:, 2], (boxes[:, 1] - a[:, 1]) / a[:, 3],
                                        torch.log(boxes[:, 2] / a[:, 2] + 1e-7), torch.log(boxes[:, 3] / a[:, 3] + 1e-7)], 1))
         loss_cls = self.focal_loss(torch.cat(cls_rows, 0), torch.cat(cls_tg, 0))
-        loss_box = F.smooth_l1_loss(torch.cat(box_rows, 0), torch.cat(box_tg, 0), reduction='mean')
+        from ....fc_ops import smooth_l1_mean
+        loss_box = smooth_l1_mean(torch.cat(box_rows, 0), torch.cat(box_tg, 0))
         return loss_cls, loss_box
 
     def forward(self, feature_backbone, targets=None, perms=None):

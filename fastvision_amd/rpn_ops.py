@@ -72,11 +72,13 @@ def rpn_sample(labels_image, positives_per_image=128, negatives_per_image=128, p
     neg = torch.nonzero(labels_image == -1).flatten()
     n_pos = min(pos.numel(), positives_per_image)
     n_neg = min(neg.numel(), max(negatives_per_image, positives_per_image + negatives_per_image - n_pos))
+    given = perm_pos is not None or perm_neg is not None
     perm_pos = torch.randperm(pos.numel(), device=labels_image.device) if perm_pos is None else perm_pos
     perm_neg = torch.randperm(neg.numel(), device=labels_image.device) if perm_neg is None else perm_neg
-    if perm_pos.numel() > pos.numel() or perm_neg.numel() > neg.numel():        # a longer permutation would index out of range on the device
-        raise ValueError(f'rpn_sample: permutations of {perm_pos.numel()} / {perm_neg.numel()} entries for {pos.numel()} positives / '
-                         f'{neg.numel()} negatives')
+    if given:      # a foreign permutation (parity tests share the reference's draws): its used prefix must index inside the candidate lists
+        for name, perm, n, cnt in (('positive', perm_pos, n_pos, pos.numel()), ('negative', perm_neg, n_neg, neg.numel())):
+            if n and (perm.numel() < n or int(perm[:n].max()) >= cnt or int(perm[:n].min()) < 0):
+                raise ValueError(f'rpn_sample: the {name} permutation does not fit {cnt} candidates ({n} to draw)')
     return pos[perm_pos[:n_pos]], neg[perm_neg[:n_neg]]
 
 

@@ -293,6 +293,15 @@ int fva_bce_loss(const float* y, const int64_t* label, const float* dense_target
                  int64_t numel, int32_t C, int32_t already_sigmoid, int32_t mean, float* loss_out, float* grad, float* workspace,
                  void* stream);
 
+/* Losses of the two-stage head (demos/faster_rcnn/models/rpn.py:8-64,303-312; fast.py:173-201), value + gradient in one launch.
+ * fva_row_loss: logits [R][C] fp32 with int64 labels[R]; mode 0 = F.cross_entropy(reduction='mean'), mode 1 = the RPN's FocalLoss
+ * (-(1 - p_t)^gamma * log p_t over softmax probabilities, alpha 1, mean); grad (optional) [R][C] = d loss / d logits;
+ * workspace: R floats.  fva_smooth_l1: F.smooth_l1_loss(pred, target, reduction='mean') (beta 1) over n elements; grad (optional)
+ * [n] = d loss / d pred; workspace: 1024 floats.  Deterministic (fixed-order sums). */
+int fva_row_loss(const float* logits, const int64_t* labels, int32_t R, int32_t C, int32_t mode, float gamma, float* loss_out, float* grad,
+                 float* workspace, void* stream);
+int fva_smooth_l1(const float* pred, const float* target, int64_t n, float* loss_out, float* grad, float* workspace, void* stream);
+
 /* Demo loss (demos/yolov3_u/utils/lossv3.py:18-119): best-anchor assignment, BCE/MSE/BCE terms, IoU>0.5
  * ignore mask, masked objectness BCE.  level.anchor_* are FEATURE-scale here and level.stride is unused.
  * loss_out[5] = {total, xy, wh, cls, conf} (unweighted parts, as the reference prints them). */
@@ -429,6 +438,12 @@ int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void*
                       void* stream);
 int32_t fva_colsum_scratch_rows(int32_t rows);   /* rows of [C] floats fva_colsum wants as scratch for its two-pass form (0: none) */
 int fva_colsum(const float* partial, int32_t rows, int C, float* out, float* scratch, void* stream);
+/* Fully connected layers of the Fast head (Linear -> ReLU, demos/faster_rcnn/models/vgg.py classifier): dY = dZ * (Z > 0)
+ * (relu = 0: dY = dZ) over rows [R][C] and per block of 32 rows the column sums of dY: partial [fva_rows_relu_bwd_rows(R)][C],
+ * added up by fva_colsum (= dbias).  The GEMMs themselves are 1x1 convolutions over R "pixels" (fva_conv_fwd_bias_act, fva_conv_dgrad,
+ * fva_conv_wgrad). */
+int32_t fva_rows_relu_bwd_rows(int32_t R);
+int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, float* partial, int32_t R, int32_t C, int32_t relu, void* stream);
 int fva_maxpool2_fwd(int dtype, const void* x, int x_pad, void* out, int out_pad, int B, int H, int W, int C, void* stream);
 int fva_maxpool2_bwd(int dtype, const void* dz, const void* x, int x_pad, void* dx, int B, int H, int W, int C, void* stream);
 

@@ -19,8 +19,9 @@ from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
 DEV = 'cuda:0'
 
 
-def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+def main(steps=None, warmup=3, cpu_baseline=True):
+    if steps is None:
+        steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     B, H, W, NC = 4, 800, 1333, 20
     torch.manual_seed(0)
     scales, ratios = [128, 256, 512], [0.5, 1, 2]
@@ -44,7 +45,7 @@ def main():
         opt.step()
         return loss
     with fastvision_amd.compute_dtype(torch.bfloat16):
-        for _ in range(3):
+        for _ in range(max(1, warmup)):
             loss = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -73,35 +74,46 @@ def main():
                 'avg_launch_ms': round(summ[dom]['ms_avg'], 4), 'launches_per_step': summ[dom]['launches'] // 3,
                 'note': 'dominant convolution class by summed launch time; exclusive timings of a 3-step probe with every kernel on one stream'}
     kernels = {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['ms_total'] / 3, 3), 'launches_per_step': v['launches'] // 3} for k, v in summ.items()}
-    # CPU baseline: the oracle (oracle/faster.py: plain torch fp32 ops over the same parameters) on a bounded sample -- one image of
-    # the same size per step, on this host's cores
-    import copy
-    from oracle import faster as OF
-    cores = len(os.sched_getaffinity(0))                      # scheduler affinity capped by the cgroup CPU quota (containers)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    cores = max(1, min(cores, 64))
-    torch.set_num_threads(cores)
-    ref = copy.deepcopy(model).cpu().float()
-    img1, tg1 = images[:1].cpu(), targets[targets[:, 0] == 0].cpu()
-    cpu_times = []
-    for i in range(2):
-        t0 = time.perf_counter()
-        for p in ref.parameters():
-            p.grad = None
-        out = OF.training_losses(ref, img1, tg1, [(None, None)] * 2)
-        torch.stack([l.reshape(()) for l in out[1:]]).sum().backward()
-        cpu_times.append(time.perf_counter() - t0)
-    cpu = {'value': round(1.0 / cpu_times[-1], 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-           'sample': f'CPU oracle (oracle/faster.py, fp32), forward + backward of 1x3x{H}x{W}: 1 warm-up + 1 timed step, {cpu_times[-1]:.2f} s'}
-    print(json.dumps({'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'workload': f'Faster R-CNN (VGG16 + RPN + Fast head) train step {B}x3x{H}x{W} bf16, {NC} classes, grad-norm clip + Nesterov SGD, synthetic',
-                      'ms_per_step': round(ms, 2), 'images_per_sec': round(B / (ms * 1e-3), 2), 'steps': steps, 'loss': round(float(loss), 4),
-                      'note': 'conv / pool / RoIAlign / matchers / proposal layer on the HIP kernels, FC layers rocBLAS via torch, '
-                              'losses and sampling torch ops; host-inclusive (each step reads sample counts back like the reference)'}))
+    cpu = None
+    if cpu_baseline:
+        # CPU baseline: the oracle (oracle/faster.py: plain torch fp32 ops over the same parameters) on a bounded sample -- one image of
+        # the same size per step, on this host's cores
+        import copy
+        from oracle import faster as OF
+        cores = len(os.sched_getaffinity(0))                      # scheduler affinity capped by the cgroup CPU quota (containers)
+        try:
+            quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+            if quota != 'max':
+                cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+        cores = max(1, min(cores, 64))
+        torch.set_num_threads(cores)
+        ref = copy.deepcopy(model).cpu().float()
+        img1, tg1 = images[:1].cpu(), targets[targets[:, 0] == 0].cpu()
+        cpu_times = []
+        for i in range(2):
+            t0 = time.perf_counter()
+            for p in ref.parameters():
+                p.grad = None
+            out = OF.training_losses(ref, img1, tg1, [(None, None)] * 2)
+            torch.stack([l.reshape(()) for l in out[1:]]).sum().backward()
+            cpu_times.append(time.perf_counter() - t0)
+        cpu = {'value': round(1.0 / cpu_times[-1], 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+               'sample': f'CPU oracle (oracle/faster.py, fp32), forward + backward of 1x3x{H}x{W}: 1 warm-up + 1 timed step, {cpu_times[-1]:.2f} s'}
+    out = {'metric': 'images/sec (4x3x800x1333) Faster R-CNN (VGG16 + RPN + Fast head) train step, 1 MI355X', 'value': round(B / (ms * 1e-3), 2),
+           'unit': 'images/sec', 'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': f'Faster R-CNN (the reference demo: VGG16 stride-16 backbone + RPN + Fast head) train step {B}x3x{H}x{W} bf16, '
+                                  f'{NC} classes, 128+128 RPN / 16+48 Fast samples per image, grad-norm clip + Nesterov SGD (BASELINE config 5)',
+                      'global_batch': B, 'parallelism': 'dp1'},
+           'roofline': roofline, 'kernels': kernels, 'loss': round(float(loss), 4),
+           'note': 'conv / pool / RoIAlign / matchers / proposal layer / fully connected layers / losses on the HIP kernels; host-inclusive '
+                   '(each step reads sample counts back like the reference)'}
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
+    print(json.dumps(out))
+    return out
 
 
 if __name__ == '__main__':

@@ -12,7 +12,8 @@ import re
 import sys
 
 CLASSES = {'conv_fwd': lambda n: ('igemm_kernel' in n and re.search(r'ELi0ELi\d+EEE', n)) or 'igemm8_kernelILi0' in n or 'igemm8_kernel<0' in n,
-           'conv_dgrad': lambda n: ('igemm_kernel' in n and re.search(r'ELi1ELi\d+EEE', n)) or 'igemm8_kernelILi1' in n or 'igemm8_kernel<1' in n,
+           'conv_dgrad': lambda n: ('igemm_kernel' in n and re.search(r'ELi[14]ELi\d+EEE', n)) or 'igemm8_kernelILi1' in n or 'igemm8_kernel<1' in n
+                                   or 'igemm8_kernelILi4' in n or 'igemm8_kernel<4' in n,
            'conv_wgrad': lambda n: 'wgrad_kernel' in n or 'wgrad8_kernel' in n or 'wgrad_reduce_kernel' in n}
 
 
@@ -45,6 +46,16 @@ def main():
         out[cls] = {'bytes_per_launch': round(rd + wr), 'read_bytes_per_launch': round(rd),
                     'write_bytes_per_launch': round(wr), 'launches_profiled': main_launches,
                     'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled (gfx950)'}
+    # step totals: every kernel's bytes, per optimizer step (adam_kernel runs once per step)
+    steps = max([f[n][0] for n in f if 'adam_kernel' in n] or [1])
+    wsteps = max([w[n][0] for n in w if 'adam_kernel' in n] or [steps])
+    total_rd = sum(2 * f[n][1] for n in f) * 1024 / steps
+    total_wr = sum(w[n][1] for n in w) * 1024 / wsteps
+    bn = lambda n: n.startswith('bn_') or '_bn_' in n or 'bn_bwd' in n or 'bn_silu' in n
+    bn_rd = sum(2 * f[n][1] for n in f if bn(n)) * 1024 / steps
+    bn_wr = sum(w[n][1] for n in w if bn(n)) * 1024 / wsteps
+    out['step'] = {'bytes_per_step': round(total_rd + total_wr), 'read_bytes_per_step': round(total_rd), 'write_bytes_per_step': round(total_wr),
+                   'batchnorm_pass_bytes_per_step': round(bn_rd + bn_wr), 'steps_profiled': steps}
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     open(sys.argv[4], 'w').write('# HBM traffic per launch (PMC), bench.py B=32 640x640 bf16, weight gradients on the launch stream (FVA_WGRAD_STREAM=0)\n\n' + '\n'.join(lines) +
                                  '\n\nPer conv class (all tile variants pooled, per conv call):\n\n```\n' + json.dumps(out, indent=1) + '\n```\n')
