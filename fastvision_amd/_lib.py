@@ -114,7 +114,7 @@ PROTOTYPES = {
     'fva_row_loss': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     'fva_smooth_l1': (_I, [_P, _P, _L, _P, _P, _P, _P]),
     'fva_rows_relu_bwd_rows': (_I, [_I]),
-    'fva_rows_relu_bwd': (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'fva_rows_relu_bwd': (_I, [_I, _P, _P, _P, _L, _P, _I, _I, _I, _P]),
     'fva_demo_loss': (_I, [_P, _I, _H, _I, _P, _P, _L, _P]),
     'fva_demo_loss_workspace': (_L, [_I, _H, _I]),
     'fva_iou_pairwise': (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _F, _P]),

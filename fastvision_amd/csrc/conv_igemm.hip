@@ -570,10 +570,17 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
     q.nblocks = cdiv(p.N, BN);
-    const int smem = NSTAGE * (BM + BN) * 128 + (BN >= 128 ? 4096 : 0);  // stages (+ k-tile offset table, wide tiles)
+    // stages (+ k-tile offset table, wide tiles: 8 bytes per k-tile -- or per half k-tile in half-row mode --, at least 4 KiB; a fully
+    // connected layer seen as a 1x1 convolution reduces over 25088 channels = 784 fp32 k-tiles)
+    constexpr int KTAB_MAX = 16384;
+    const int nent = (p.halfrow ? 2 : 1) * p.ktiles;
+    if (BN >= 128 && nent * 8 > KTAB_MAX) return fva_fail(FVA_ERR_ARG, "igemm: %d k-tiles exceed the offset table (%d)", p.ktiles, KTAB_MAX / 8);
+    const int ktab_bytes = BN >= 128 ? (nent * 8 > 4096 ? (nent * 8 + 255) & ~255 : 4096) : 0;
+    const int smem = NSTAGE * (BM + BN) * 128 + ktab_bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  NSTAGE * (BM + BN) * 128 + (BN >= 128 ? KTAB_MAX : 0));
         attr_done = true;
     }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 // [R][C] (any C that is a multiple of the 16-byte chunk) and, per block of 32 rows, the column sums of dY (= partial dbias).
 template <typename T>
 __global__ __launch_bounds__(256) void rows_relu_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z, T* __restrict__ dy,
-                                                            float* __restrict__ partial, int R, int C, int relu) {
+                                                            float* __restrict__ partial, int R, int C, int relu, int64_t dy_stride) {
     constexpr int EPC = Vec16<T>::N;
     const int cc = blockIdx.x * 256 + threadIdx.x;
     if (cc * EPC >= C) return;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rows_relu_bwd_kernel(const T* __restrict_
         }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] += o.get(e);
-        *(Vec16<T>*)(dy + off) = o;
+        *(Vec16<T>*)(dy + (int64_t)r * dy_stride + cc * EPC) = o;
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) partial[(int64_t)blockIdx.y * C + cc * EPC + e] = acc[e];
@@ -200,17 +200,18 @@ int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void*
 
 int32_t fva_rows_relu_bwd_rows(int32_t R) { return cdiv(R, 32); }
 
-int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, float* partial, int32_t R, int32_t C, int32_t relu, void* stream) {
+int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, int64_t dy_stride, float* partial, int32_t R, int32_t C, int32_t relu,
+                      void* stream) {
     int rc = chan_ok("fva_rows_relu_bwd", dtype, C, false);
     if (rc) return rc;
-    if (!dz || (relu && !z) || !dy || !partial || R <= 0) return fva_fail(FVA_ERR_ARG, "fva_rows_relu_bwd: bad argument");
+    if (!dz || (relu && !z) || !dy || !partial || R <= 0 || dy_stride < C) return fva_fail(FVA_ERR_ARG, "fva_rows_relu_bwd: bad argument");
     const int epc = dtype == FVA_BF16 ? 8 : 4;
     const dim3 grid(cdiv(C / epc, 256), cdiv(R, 32));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(rows_relu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dy, partial, R, C, relu);
+        hipLaunchKernelGGL(rows_relu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dy, partial, R, C, relu, dy_stride);
     else
-        hipLaunchKernelGGL(rows_relu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, (const float*)z, (float*)dy, partial, R, C, relu);
+        hipLaunchKernelGGL(rows_relu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, (const float*)z, (float*)dy, partial, R, C, relu, dy_stride);
     FVA_LAUNCH_CHECK("rows_relu_bwd_kernel");
     return FVA_OK;
 }

@@ -86,10 +86,13 @@ class Fast(nn.Module):
                                                        self.fast_positives_per_image, self.fast_negatives_per_image, perms=perms)
             pos_rois = torch.cat([positives[:, :1], _xyxy(positives[:, 1:5])], 1)
             neg_rois = torch.cat([negatives[:, :1], _xyxy(negatives[:, 1:5])], 1)
-            positive_cls, positive_box = self._heads(feature_backbone, pos_rois)
+            # the reference runs the head twice (fast.py:227-240: positives, then negatives); rows are independent, so ONE pass over
+            # both sets gives the same logits and streams the 205 MB of classifier weights once
+            n_pos = pos_rois.size(0)
+            all_cls, all_box = self._heads(feature_backbone, torch.cat([pos_rois, neg_rois], 0))
+            positive_cls, positive_box, negative_cls = all_cls[:n_pos], all_box[:n_pos], all_cls[n_pos:]
             if self.fast_multi_reg_head:
                 positive_box = self._pick_class_box(positive_box, positives[:, 9] + 1)
-            negative_cls, _ = self._heads(feature_backbone, neg_rois)
             return self.compute_loss(positive_cls, negative_cls, positive_box, positives[:, 5:9], positives[:, 9:10])
         predicts = []
         std = torch.tensor(BOX_STD, device=device)

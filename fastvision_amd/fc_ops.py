@@ -6,7 +6,7 @@ The reference's Fast head runs RoI features through the VGG classifier ``Linear(
 
     linear_relu(x, lin)        relu(x @ W^T + b): a 1x1 convolution over R "pixels" on the implicit-GEMM kernel with the bias + ReLU
                                epilogue (fva_conv_fwd_bias_act); backward: ReLU mask + bias gradient in one pass
-                               (fva_rows_relu_bwd + fva_colsum), then fva_conv_dgrad / fva_conv_wgrad (wgrad on the side stream)
+                               (fva_rows_relu_bwd + fva_colsum), then fva_conv_dgrad / fva_conv_wgrad
     linear(x, lin)             x @ W^T + b without activation, fp32 output: the detection head's biased 1x1 convolution (ops.HeadFn)
     cross_entropy_mean / focal_mean / smooth_l1_mean      value and gradient in one launch (fva_row_loss / fva_smooth_l1)
 
@@ -18,7 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .ops import HeadFn, _code, _p, _stream, get_compute_dtype, packed_weights, require_gpu, wgrad_stream
+from .ops import HeadFn, _code, _p, _stream, get_compute_dtype, packed_weights, require_gpu
 
 __all__ = ['linear_relu', 'linear', 'cross_entropy_mean', 'focal_mean', 'smooth_l1_mean']
 
@@ -42,7 +42,7 @@ class LinearReLUFn(torch.autograd.Function):
         N = weight.shape[0]
         xs = x.detach()
         xs = xs if (xs.dtype == dtype and xs.is_contiguous()) else xs.to(dtype).contiguous()
-        d = _lib.ConvDesc(_code(dtype), 1, R, 1, K, N, 1, 1, 0, 0)            # [1][R][1][K] NHWC, no halo
+        d = _lib.ConvDesc(_code(dtype), 1, R, 1, K, N, 1, 1, 0, 1)            # x: [1][R][1][K] NHWC without halo; dY gets a border of 1
         wf, wd = _packed_linear(weight, d, dtype)
         z = torch.empty((R, N), dtype=dtype, device=x.device)
         _lib.call('fva_conv_fwd_bias_act', C.byref(d), _p(xs), _p(wf), _p(bias.detach().float().contiguous()), 1, _p(z), 0, _stream())
@@ -56,10 +56,10 @@ class LinearReLUFn(torch.autograd.Function):
         lib = _lib.load()
         R, N, dev, code = d.H, d.Cout, z.device, _code(dtype)
         g = dz if (dz.dtype == dtype and dz.is_contiguous()) else dz.to(dtype).contiguous()
-        dy = torch.empty((R, N), dtype=dtype, device=dev)
+        dy = torch.zeros((1, R + 2, 3, N), dtype=dtype, device=dev)           # halo buffer (W = 1): the kernels want a zero border
         rows = lib.fva_rows_relu_bwd_rows(R)
         part = torch.empty((rows, N), dtype=torch.float32, device=dev)
-        _lib.call('fva_rows_relu_bwd', code, _p(g), _p(z), _p(dy), _p(part), R, N, 1, _stream())
+        _lib.call('fva_rows_relu_bwd', code, _p(g), _p(z), C.c_void_p(dy[0, 1, 1].data_ptr()), 3 * N, _p(part), R, N, 1, _stream())
         dbias = torch.empty(N, dtype=torch.float32, device=dev)
         srows = lib.fva_colsum_scratch_rows(rows)
         scratch = torch.empty((srows, N), dtype=torch.float32, device=dev) if srows else None
@@ -67,7 +67,10 @@ class LinearReLUFn(torch.autograd.Function):
         dw = torch.empty((wshape[0], wshape[1], 1, 1), dtype=torch.float32, device=dev)
         wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.call('fva_conv_wgrad', C.byref(d), _p(xs), _p(dy), _p(dw), 0, _p(ws), wsb, wgrad_stream((xs, dy, ws), ctx.weight))
+        # on the launch stream, not the side stream: a fully connected layer may be applied several times in one forward pass (the
+        # reference runs positives and negatives through the head separately), and autograd then SUMS the weight gradients of the
+        # calls on the launch stream -- it must find them finished
+        _lib.call('fva_conv_wgrad', C.byref(d), _p(xs), _p(dy), _p(dw), 0, _p(ws), wsb, _stream())
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, d.Cin), dtype=dtype, device=dev)

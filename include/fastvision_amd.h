@@ -439,11 +439,13 @@ int fva_bias_relu_bwd(int dtype, const void* dz, const void* z, int z_pad, void*
 int32_t fva_colsum_scratch_rows(int32_t rows);   /* rows of [C] floats fva_colsum wants as scratch for its two-pass form (0: none) */
 int fva_colsum(const float* partial, int32_t rows, int C, float* out, float* scratch, void* stream);
 /* Fully connected layers of the Fast head (Linear -> ReLU, demos/faster_rcnn/models/vgg.py classifier): dY = dZ * (Z > 0)
- * (relu = 0: dY = dZ) over rows [R][C] and per block of 32 rows the column sums of dY: partial [fva_rows_relu_bwd_rows(R)][C],
+ * (relu = 0: dY = dZ) over rows [R][C] (dY rows dy_stride elements apart: the interior column of a halo buffer [1][R+2][3][C], which
+ * is what fva_conv_wgrad / fva_conv_dgrad read) and per block of 32 rows the column sums of dY: partial [fva_rows_relu_bwd_rows(R)][C],
  * added up by fva_colsum (= dbias).  The GEMMs themselves are 1x1 convolutions over R "pixels" (fva_conv_fwd_bias_act, fva_conv_dgrad,
  * fva_conv_wgrad). */
 int32_t fva_rows_relu_bwd_rows(int32_t R);
-int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, float* partial, int32_t R, int32_t C, int32_t relu, void* stream);
+int fva_rows_relu_bwd(int dtype, const void* dz, const void* z, void* dy, int64_t dy_stride, float* partial, int32_t R, int32_t C, int32_t relu,
+                      void* stream);
 int fva_maxpool2_fwd(int dtype, const void* x, int x_pad, void* out, int out_pad, int B, int H, int W, int C, void* stream);
 int fva_maxpool2_bwd(int dtype, const void* dz, const void* x, int x_pad, void* dx, int B, int H, int W, int C, void* stream);
 
