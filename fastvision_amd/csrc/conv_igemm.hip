@@ -104,7 +104,7 @@ __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
 // the previous step's store, each load pays a full memory round trip (measured: +60 us on a 100 us dgrad launch).
 template <int EPI, int BM, int BN, int NT, int PITCH, typename OutPixel>
 __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem, int tid, int m0, int n0, int mblk, OutPixel&& out_pixel,
-                                                const bf16x8* y_pre = nullptr) {
+                                                const bf16x8* y_pre = nullptr, const bf16x8* a_pre = nullptr) {
     constexpr int CPR = BN / 8, ITERS = BM * CPR / NT, GROUP = 8, RSTEP = NT / CPR;
     static_assert(NT % CPR == 0 && ITERS % GROUP == 0, "a thread keeps its column chunk; whole groups");
     bf16_t* out = (bf16_t*)p.out;
@@ -130,8 +130,13 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
             oi[j] = ok[j] ? out_pixel(m) * p.out_pitch + n : 0;     // masked steps read element 0: no branch around a load
         }
         if (has_add) {
+            if (a_pre != nullptr) {
 #pragma unroll
-            for (int j = 0; j < GROUP; ++j) ad[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi[j]);
+                for (int j = 0; j < GROUP; ++j) ad[j] = a_pre[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < GROUP; ++j) ad[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi[j]);
+            }
         }
         if constexpr (EPI == EPI_BNB) {
             if (y_pre != nullptr) {       // fetched before the k loop (ITERS == GROUP): the launch's rounds of tiles run in lockstep,
@@ -307,9 +312,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(sB + (i * NW + w) * 1024), 16, 0, 0);
     };
 
-    // EPI_BNB (bf16): this thread's eight 16-byte pieces of the producer's y tile, in the store loop's (row, chunk) order
-    bf16x8 y_pre[8];
-    if constexpr (EPI == EPI_BNB && sizeof(T) == 2) {
+    // dgrad epilogues (bf16): this thread's eight 16-byte pieces of the residual addend and (EPI_BNB) of the producer's y tile, in
+    // the store loop's (row, chunk) order, fetched BEFORE the k loop: the 1x1 dgrads of the residual blocks reduce over two or
+    // four k-tiles only and are all epilogue -- reads issued there are exposed (the rounds of tiles run in lockstep)
+    bf16x8 y_pre[8], a_pre[8];
+    constexpr bool PREFETCH = (EPI == EPI_BNB || EPI == EPI_PLAIN) && sizeof(T) == 2;
+    if constexpr (PREFETCH) {
         constexpr int CPR = BN / 8, RSTEP = NT / CPR;
         static_assert(BM * CPR / NT == 8, "the prefetch covers the whole store loop");
         const int cc = tid % CPR, r0 = tid / CPR;
@@ -329,7 +337,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 }
                 oi = pixel * p.out_pitch + n;
             }
-            y_pre[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
+            if constexpr (EPI == EPI_BNB) y_pre[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
+            if (p.addend != nullptr) a_pre[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi);
         }
     }
 
@@ -561,7 +570,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
         __syncthreads();
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr);
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr);
     }
 }
 
