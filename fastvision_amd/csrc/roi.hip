@@ -65,8 +65,15 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
     const float x1 = roi[1] * p.scale, y1 = roi[2] * p.scale, x2 = roi[3] * p.scale, y2 = roi[4] * p.scale;
     const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
     const float bin_h = roi_h / (float)p.PH, bin_w = roi_w / (float)p.PW;
-    const int grid_h = p.sampling > 0 ? p.sampling : (int)ceilf(roi_h / (float)p.PH);
-    const int grid_w = p.sampling > 0 ? p.sampling : (int)ceilf(roi_w / (float)p.PW);
+    // adaptive sampling grid (ceil(roi / bins) samples per bin and axis), bounded: a box with a non-finite or absurd extent -- user
+    // input, the RPN clamps its own proposals to the map -- must not make the kernel walk 10^9 samples.  64 samples per bin and axis
+    // cover boxes of 448 cells at 7 bins; larger boxes are sampled on the 64-grid (a deviation from torchvision only out there).
+    constexpr int MAX_GRID = 64;
+    const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
+    int grid_h = p.sampling > 0 ? p.sampling : (finite ? (int)ceilf(fminf(roi_h, 1e6f) / (float)p.PH) : 1);
+    int grid_w = p.sampling > 0 ? p.sampling : (finite ? (int)ceilf(fminf(roi_w, 1e6f) / (float)p.PW) : 1);
+    grid_h = grid_h > MAX_GRID ? MAX_GRID : grid_h;
+    grid_w = grid_w > MAX_GRID ? MAX_GRID : grid_w;
     const float inv_count = 1.f / (float)max(grid_h * grid_w, 1);
     const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
     const int nbins = p.PH * p.PW;

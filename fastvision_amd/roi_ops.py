@@ -53,6 +53,8 @@ class RoIAlignFn(torch.autograd.Function):
 def roi_align(features, boxes, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
     if aligned:
         raise NotImplementedError('roi_align: aligned=True is not on the reference path (fast.py uses the default)')
+    if sampling_ratio > 64:
+        raise ValueError('roi_align: sampling_ratio above 64 samples per bin and axis is not supported')
     if isinstance(boxes, (list, tuple)):        # torchvision's list-of-[L,4] form: prepend the image index
         boxes = torch.cat([torch.cat([torch.full((b.size(0), 1), i, dtype=b.dtype, device=b.device), b], 1) for i, b in enumerate(boxes)], 0)
     return RoIAlignFn.apply(features, boxes, output_size, spatial_scale, sampling_ratio)

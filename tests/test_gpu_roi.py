@@ -94,3 +94,20 @@ def test_reference_size_adjoint_property_and_timing():
     torch.cuda.synchronize()
     print(f'roi_align fwd {B}x{C}x{H}x{W}, K={K}: {ev[0].elapsed_time(ev[1]) * 100:.1f} us per call incl. the NCHW -> NHWC pack, '
           f'{ev[2].elapsed_time(ev[3]) * 100:.1f} us on a halo NHWC view (25.7 MB written)')
+
+
+def test_non_finite_and_huge_boxes_terminate():
+    """A box with an infinite or absurd extent (user input; the RPN clamps its own proposals) must neither spin nor fault: the sampling
+    grid is bounded at 64 x 64 per bin.  Finite rows of the same call are unaffected."""
+    from fastvision_amd.roi_ops import roi_align
+    from oracle import roi_align as R
+    rng = np.random.default_rng(9)
+    feat = torch.from_numpy(rng.standard_normal((1, 64, 12, 12)).astype(np.float32))
+    boxes = np.array([[0, 1.0, 1.0, 8.0, 9.0], [0, 0.0, 0.0, float('inf'), 5.0], [0, 2.0, 2.0, 1e30, 1e30], [0, float('nan'), 0.0, 4.0, 4.0]], np.float32)
+    out = roi_align(feat.to(DEV), torch.from_numpy(boxes).to(DEV), (7, 7))
+    torch.cuda.synchronize()
+    want = R.roi_align(feat.numpy(), boxes[:1], (7, 7))
+    np.testing.assert_allclose(out[0].cpu().numpy(), want[0], rtol=1e-5, atol=2e-5)
+    assert out.shape == (4, 64, 7, 7)
+    with pytest.raises(ValueError):
+        roi_align(feat.to(DEV), torch.from_numpy(boxes[:1]).to(DEV), (7, 7), sampling_ratio=100)
