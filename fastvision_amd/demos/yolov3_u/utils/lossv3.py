@@ -71,6 +71,7 @@ class ComputeLoss(nn.Module):
         super().__init__()
         self.verbose = verbose
         self.last_parts = None
+        self._anchors = None                     # (key, host copy): reading model.anchors is a device sync, and not allowed inside a graph capture
 
     def get_model(self, model):
         return model.module if hasattr(model, 'module') else model
@@ -78,7 +79,10 @@ class ComputeLoss(nn.Module):
     def forward(self, predict_layers, target_all, model):
         model = self.get_model(model)
         require_gpu(predict_layers[0], 'ComputeLoss')
-        anchors = [[(float(w), float(h)) for w, h in a.reshape(-1, 2).tolist()] for a in model.anchors]   # feature scale
+        key = tuple((a.data_ptr(), a._version) for a in model.anchors)
+        if self._anchors is None or self._anchors[0] != key:
+            self._anchors = (key, [[(float(w), float(h)) for w, h in a.reshape(-1, 2).tolist()] for a in model.anchors])   # feature scale
+        anchors = self._anchors[1]
         if target_all.shape[0] == 0:
             raise RuntimeError('ComputeLoss needs at least one target (the reference fails on an empty image too, lossv3.py:94)')
         tg = target_all.detach().to(device=predict_layers[0].device, dtype=torch.float32).contiguous()

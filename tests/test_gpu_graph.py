@@ -125,3 +125,42 @@ def test_graphed_step_refuses_what_it_cannot_capture():
     step = GraphedTrainStep(net, crit, opt, im.to(DEV), tg.to(DEV), max_targets=tg.shape[0])
     with pytest.raises(ValueError):
         step(im.to(DEV), torch.cat([tg, tg]).to(DEV))                                                 # more targets than captured
+
+
+def test_graphed_demo_step_is_bit_identical_with_eager():
+    """The demo surface (YoloV3 + ComputeLoss, demos/yolov3_u/utils/fit.py:52-66): ComputeLoss assigns every target row, so the step
+    is captured at its exact target count; the anchors it reads from the model are cached on the host before capture."""
+    import fastvision_amd
+    from fastvision_amd import FusedAdam
+    from fastvision_amd.demos.yolov3_u.models import YoloV3
+    from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+    from fastvision_amd.graphs import GraphedTrainStep
+    from fastvision_amd.synthetic import coco_anchors_feature, synthetic_batch
+    im, tg = synthetic_batch(2, 128, seed=5)
+    im, tg = im.to(DEV), tg.to(DEV)
+    im2 = torch.flip(im, dims=[3]).contiguous()
+
+    def make_demo():
+        torch.manual_seed(3)
+        net = YoloV3(anchors=tuple(a.to(DEV) for a in coco_anchors_feature())).to(DEV).train()
+        cl = ComputeLoss()
+        opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4, capturable=True)
+        return net, (lambda p, t: cl(p, t, net)), opt
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        net, loss_fn, opt = make_demo()
+        want = []
+        for x in (im, im2, im):
+            pred = net(x)
+            opt.zero_grad()
+            loss = loss_fn(pred, tg)
+            loss.backward()
+            opt.step()
+            want.append(loss.detach().clone())
+        net2, loss_fn2, opt2 = make_demo()
+        step = GraphedTrainStep(net2, loss_fn2, opt2, im, tg)
+        got = [step(x, tg).clone() for x in (im, im2, im)]
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), (a, b)
+    for (k, a), (_, b) in zip(net2.state_dict().items(), net.state_dict().items()):
+        assert torch.equal(a, b), k
