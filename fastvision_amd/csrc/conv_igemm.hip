@@ -50,6 +50,9 @@ struct IgemmParams {
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_rstd;
     float* bnb_part;
     int bnb_row0, bnb_C;
+    long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
+    int stamp_rows;
+    int skew;            // experiment: blocks of the second residency slot start half a tile period late
 };
 
 // coefficients of eight (bf16 chunk) consecutive channels for the fused BatchNorm-backward statistics
@@ -63,6 +66,32 @@ __device__ __forceinline__ void bnb_load(const IgemmParams& p, int n, BnbCoef& k
         c = c < p.N ? c : p.N - 1;
         c = c >= p.bnb_C ? c - p.bnb_C : c;      // paired stride-2 dgrad: the columns are two pixels' channels
         k.sc[e] = p.bnb_scale[c]; k.sh[e] = p.bnb_shift[c]; k.mu[e] = p.bnb_mean[c]; k.rs[e] = p.bnb_rstd[c];
+    }
+}
+// The same coefficients staged in LDS once per tile, [4][BN] floats indexed by the tile column: read from global memory in the
+// epilogue, the 32 dependent loads per thread sat in front of the statistics arithmetic (1-2 us per tile, tools/tile_timing.py pw).
+template <int BN, int NT>
+__device__ __forceinline__ void bnb_fill_lds(const IgemmParams& p, float* tab, int tid, int n0) {
+    for (int i = tid; i < 4 * BN; i += NT) {
+        const int which = i / BN, col = i - which * BN;
+        int c = n0 + col;
+        c = c < p.N ? c : p.N - 1;
+        c = c >= p.bnb_C ? c - p.bnb_C : c;
+        const float* src = which == 0 ? p.bnb_scale : which == 1 ? p.bnb_shift : which == 2 ? p.bnb_mean : p.bnb_rstd;
+        tab[i] = src[c];
+    }
+}
+template <int BN>
+__device__ __forceinline__ void bnb_load_lds(const float* tab, int col, BnbCoef& k) {
+    const f32x4* t = (const f32x4*)(tab + col);
+    const f32x4 a0 = t[0], a1 = t[1], b0 = t[BN / 4], b1 = t[BN / 4 + 1], c0 = t[2 * BN / 4], c1 = t[2 * BN / 4 + 1], d0 = t[3 * BN / 4],
+                d1 = t[3 * BN / 4 + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k.sc[e] = a0[e]; k.sc[4 + e] = a1[e];
+        k.sh[e] = b0[e]; k.sh[4 + e] = b1[e];
+        k.mu[e] = c0[e]; k.mu[4 + e] = c1[e];
+        k.rs[e] = d0[e]; k.rs[4 + e] = d1[e];
     }
 }
 // the block's partial sums, gathered per 16-byte column chunk by the threads of the store loop: red[which][group][BN] in LDS ->
@@ -104,7 +133,7 @@ __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
 // the previous step's store, each load pays a full memory round trip (measured: +60 us on a 100 us dgrad launch).
 template <int EPI, int BM, int BN, int NT, int PITCH, typename OutPixel>
 __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem, int tid, int m0, int n0, int mblk, OutPixel&& out_pixel,
-                                                const bf16x8* y_pre = nullptr, const bf16x8* a_pre = nullptr) {
+                                                const bf16x8* y_pre = nullptr, const bf16x8* a_pre = nullptr, const float* coef_lds = nullptr) {
     constexpr int CPR = BN / 8, ITERS = BM * CPR / NT, GROUP = 8, RSTEP = NT / CPR;
     static_assert(NT % CPR == 0 && ITERS % GROUP == 0, "a thread keeps its column chunk; whole groups");
     bf16_t* out = (bf16_t*)p.out;
@@ -115,7 +144,8 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
     BnbCoef kc;
     float b1[8], b2[8];
     if constexpr (EPI == EPI_BNB) {
-        bnb_load(p, n, kc);
+        if (coef_lds != nullptr) bnb_load_lds<BN>(coef_lds, cc * 8, kc);
+        else bnb_load(p, n, kc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) b1[e] = b2[e] = 0.f;
     }
@@ -229,6 +259,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WN, wc = w % WN;
+    auto stamp = [&](int i) {   // 0 entry, 1 pointers / prefetches issued, 2 first k-tile landed, 3 k loop done, 4 tile staged in LDS, 5 exit
+        if (p.stamps && tid == 0 && (int)blockIdx.x < p.stamp_rows) p.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
+    };
+    stamp(0);
+    if (p.skew && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // XCD-aware block order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles.
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -267,7 +304,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     // tiles tabulate them once in LDS (no division / dynamic kernarg indexing in the loop); the thin 256x64 tile
     // keeps its LDS at exactly 2 x 40 KiB so that two blocks fit a CU, and selects the tap with a short unrolled scan.
     constexpr bool USE_KTAB = BN >= 128;
-    int* ktab = (int*)(smem + NSTAGE * STAGE);
+    constexpr int COEF_BYTES = (EPI == EPI_BNB && IS_BF16 && BN >= 128) ? 4 * BN * 4 : 0;   // bnb_fill_lds (the 256x64 tile has no LDS to spare)
+    float* coef_tab = (float*)(smem + NSTAGE * STAGE);   // EPI_BNB: [4][BN] floats, see bnb_fill_lds
+    int* ktab = (int*)(smem + NSTAGE * STAGE + COEF_BYTES);
+    if constexpr (COEF_BYTES > 0) bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);
     if constexpr (USE_KTAB) {
         const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
         for (int e = tid; e < nent; e += NT) {
@@ -357,26 +397,25 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 for (int e = 0; e < 16; ++e) acc.a[i][j][e] = 0.f;
     }
 
-    // ---- main loop: NSTAGE-deep LDS ring (2 in every build: deeper rings leave one block per CU and measured slower),
-    // one raw barrier per k-tile.  Tiles kt+1 .. kt+NSTAGE-2 stay in flight
-    // across the barrier (counted vmcnt: LDS-DMA retires in issue order), tile kt+NSTAGE-1 is issued right after
-    // it into the stage every wave has just finished reading.
+    // ---- main loop: two LDS stages, one raw barrier per k-tile (deeper rings leave one block per CU and measured slower).  Both
+    // stages are free at entry, so k-tiles 0 and 1 are issued together (the 1x1 layers reduce over 1-16 k-tiles: every exposed DMA
+    // round trip counts); from then on k-tile kt+1 is issued right after the barrier of kt, into the stage every wave has just
+    // finished reading (counted vmcnt: LDS-DMA retires in issue order).
+    static_assert(NSTAGE == 2, "the loop below is written for two stages");
     constexpr int LPT = A_ITERS + B_ITERS;  // DMA instructions per wave and tile
-#pragma unroll
-    for (int i = 0; i < NSTAGE - 1; ++i)
-        if (i < p.ktiles) load_tile(i, i);
-    int st_cur = 0, st_next = NSTAGE - 1;
+    load_tile(0, 0);
+    if (p.ktiles > 1) load_tile(1, 1);
+    int st_cur = 0;
+    stamp(1);
     for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int ahead = p.ktiles - 1 - kt;  // tiles issued after kt that may stay in flight
-        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
-        else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<LPT>();
+        if (kt == 0 && p.ktiles > 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < p.ktiles) load_tile(kt + NSTAGE - 1, st_next);
+        if (kt == 0) stamp(2);
+        if (kt >= 1 && kt + 1 < p.ktiles) load_tile(kt + 1, st_cur ^ 1);
         const char* sA = smem + st_cur * STAGE;
         const char* sB = sA + A_BYTES;
-        st_next = st_cur;
-        st_cur = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+        st_cur ^= 1;
         if constexpr (IS_BF16) {
             const int r = lane & 15, g = lane >> 4, sr = (r >> 1) & 7;
             const char* pa = sA + (wr * 64 + r) * 128;
@@ -420,6 +459,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
     }
     __syncthreads();  // LDS is free for the epilogue
+    stamp(3);
 
     const int wrow0 = wr * 64, wcol0 = wc * 64;
 
@@ -562,6 +602,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     } else {
         // bf16: transpose through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
+        if constexpr (EPI == EPI_BNB && COEF_BYTES == 0) {
+            // thin tile (its two stages are exactly half a CU's LDS): the coefficient table goes behind the staged tile now that the
+            // ring is free -- one global load per thread under the transposition instead of 32 dependent ones in the store loop
+            coef_tab = (float*)(smem + BM * PITCH);
+            bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);
+        }
         foreach_acc(acc, lane, [&](int row, int col, int, float v) {
             if constexpr (EPI == EPI_BNACT) {
                 const int n = n0 + wcol0 + col < p.N ? n0 + wcol0 + col : p.N - 1;
@@ -570,8 +616,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
         __syncthreads();
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr);
+        stamp(4);
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr,
+                                                coef_tab);
     }
+    stamp(5);
 }
 
 template <typename T, int BM, int BN, int EPI, int NSTAGE>
@@ -579,17 +628,23 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
     q.nblocks = cdiv(p.N, BN);
+    static const bool stamp_tiles = [] { const char* e = getenv("FVA_STAMP_IGEMM"); return e && atoi(e) != 0; }();   // tools/tile_timing.py pw
+    q.stamps = stamp_tiles ? fva_debug_stamps_ptr() : nullptr;
+    q.stamp_rows = stamp_tiles ? fva_debug_stamps_rows() : 0;
+    static const int skew = [] { const char* e = getenv("FVA_SKEW"); return e ? atoi(e) : 0; }();
+    q.skew = skew;
     // stages (+ k-tile offset table, wide tiles: 8 bytes per k-tile -- or per half k-tile in half-row mode --, at least 4 KiB; a fully
     // connected layer seen as a 1x1 convolution reduces over 25088 channels = 784 fp32 k-tiles)
     constexpr int KTAB_MAX = 16384;
     const int nent = (p.halfrow ? 2 : 1) * p.ktiles;
     if (BN >= 128 && nent * 8 > KTAB_MAX) return fva_fail(FVA_ERR_ARG, "igemm: %d k-tiles exceed the offset table (%d)", p.ktiles, KTAB_MAX / 8);
     const int ktab_bytes = BN >= 128 ? (nent * 8 > 4096 ? (nent * 8 + 255) & ~255 : 4096) : 0;
-    const int smem = NSTAGE * (BM + BN) * 128 + ktab_bytes;
+    constexpr int coef_bytes = (EPI == EPI_BNB && sizeof(T) == 2 && BN >= 128) ? 4 * BN * 4 : 0;
+    const int smem = NSTAGE * (BM + BN) * 128 + ktab_bytes + coef_bytes;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  NSTAGE * (BM + BN) * 128 + (BN >= 128 ? KTAB_MAX : 0));
+                                  NSTAGE * (BM + BN) * 128 + (BN >= 128 ? KTAB_MAX : 0) + coef_bytes);
         attr_done = true;
     }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
@@ -688,6 +743,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
         const int m0 = mblk * BM, n0 = nblk * BN;
         __syncthreads();   // ktab is written / the previous tile's epilogue is done with LDS
+        float* coef_tab = (float*)(smem + EPI_BYTES + 4096);
+        if constexpr (EPI == EPI_BNB) bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);   // read in the epilogue, many barriers later
 
         // ---- per-lane source rows of the LDS-DMA pieces: piece (i, w) of a half-tile = its rows (i*8 + w)*8 .. +8 ---
         // (32-bit byte offsets from the tensor bases: the host checks that both operands are smaller than 2 GiB)
@@ -938,12 +995,12 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
         });
         __syncthreads();
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, m0, n0, mblk, out_pixel);
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, m0, n0, mblk, out_pixel, nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
     }
     stamp(3);
 }
 
-constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16) + 4096;   // the epilogue's transposed tile (> 2 staging buffers) + k table
+constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16) + 4096 + 4096;   // the epilogue's transposed tile (> 2 staging buffers) + k table + bnb_fill_lds table
 
 // Stream-K scratch, registered once by the caller (fva_conv_set_workspace): [grid] slabs of 256 KiB + flags.
 struct SkWorkspace {

@@ -157,6 +157,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     issue_step(0);
     if (steps > 1) decode_step(1);
     if constexpr (IS_BF16) {
+        // both stages are free at entry: the second k-step's DMA does not wait for the first barrier (a block of a 1x1 layer
+        // runs 7-13 k-steps, every exposed round trip counts)
+        if (steps > 1) {
+            issue_step(1);
+            if (steps > 2) decode_step(2);
+        }
         // lane-constant LDS addresses of the transposed reads (see the mapping note below); stage, operand and the
         // 32-pixel half of the tile go into the instruction's immediate offset, so the loop does no address math
         const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
@@ -177,9 +183,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         // block and receives column (lane&15) of the 4 rows; two reads (k = 8g+0..3, 8g+4..7) make one MFMA fragment
         auto iteration = [&](int st, auto stage_tag) {
             constexpr int SO = decltype(stage_tag)::value * STAGE;
-            wait_vm0();
+            if (st == 0 && steps > 1) wait_vmcnt_n<8>();   // k-step 1 (8 DMA instructions) stays in flight
+            else wait_vm0();
             __builtin_amdgcn_s_barrier();
-            if (st + 1 < steps) issue_step(decltype(stage_tag)::value ^ 1);
+            if (st >= 1 && st + 1 < steps) issue_step(decltype(stage_tag)::value ^ 1);
             bf16x8 af[2][4], bfr[2][4];
 #define FVA_TR_PAIR(KK, TT)                                                                                            \
     af[KK][TT] = cat8(tr_read<SO + KK * 8192>(ra[0][TT]), tr_read<SO + KK * 8192>(ra[1][TT]));                           \
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             FVA_TR_PAIR(0, 0) FVA_TR_PAIR(0, 1) FVA_TR_PAIR(0, 2) FVA_TR_PAIR(0, 3)
             FVA_TR_PAIR(1, 0) FVA_TR_PAIR(1, 1) FVA_TR_PAIR(1, 2) FVA_TR_PAIR(1, 3)
 #undef FVA_TR_PAIR
-            if (st + 2 < steps) decode_step(st + 2);
+            if (st >= 1 && st + 2 < steps) decode_step(st + 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

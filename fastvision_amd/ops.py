@@ -272,7 +272,7 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
             and src.M == d.B * d.H * d.W and src.d.Cout == d.Cin and not torch.is_grad_enabled()):
         rows = _lib.load().fva_conv_dgrad_stat_rows(C.byref(d))
         if rows > 0:
-            part = torch.empty((_lib.load().fva_bn_partial_rows(rows) if rows > 2048 else rows, 2, d.Cin), dtype=torch.float32, device=dx.device)
+            part = torch.empty((_lib.load().fva_bn_partial_rows(rows), 2, d.Cin), dtype=torch.float32, device=dx.device)
             fs = _fuse_struct(src, part)
             _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
             src.fused = (part, rows, dx.data_ptr(), dx)
@@ -458,7 +458,7 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
         part, nb = fused[0], fused[1]              # the consumer's dgrad epilogue has already summed dU and dU * xhat
     else:
         nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
-        part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+        part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
                   _p(part), nb, s.M, Cout, _stream())
     del fused
@@ -580,7 +580,7 @@ class StemFn(torch.autograd.Function):
             # fused bf16 path: both BatchNorm-backward passes recompute conv0 from the packed image, dY lands in a halo buffer
             w = ctx.weight
             nb = lib.fva_stem_fused_blocks(B, H, W)
-            part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+            part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
             _lib.call('fva_stem_fused', 2, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), None, None,
                       _p(part), B, Cin, H, W, _stream())
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -596,7 +596,7 @@ class StemFn(torch.autograd.Function):
             _lib.call('fva_stem_wgrad_mfma', _p(ctx.img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
             return None, raw[:, :3, :Cin, :].permute(0, 2, 3, 1).contiguous(), dgamma, dbeta, None, None, None
         nb = lib.fva_bn_bwd_blocks(code, M, Cout)
-        part = torch.empty((nb, 2, Cout), dtype=torch.float32, device=dev)
+        part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(part),
                   nb, M, Cout, _stream())
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)

@@ -211,8 +211,8 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
                            int64_t M, int C, void* stream);
 int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
 /* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2.  partial: the table of
- * fva_bn_silu_bwd_reduce (<= 2048 rows) or of fva_conv_dgrad_bnstats; a table of more than 2048 rows must have been allocated
- * with fva_bn_partial_rows(nblocks) rows (it is folded in parallel first, into doubles kept behind the table). */
+ * fva_bn_silu_bwd_reduce or of fva_conv_dgrad_bnstats, ALLOCATED with fva_bn_partial_rows(nblocks) rows: a long table (1024 rows
+ * or more) is folded in parallel first, into doubles kept behind the nblocks rows the producer fills. */
 int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
                         const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                         void* stream);

@@ -68,7 +68,7 @@ def test_dgrad_bnstats_equals_reduce_pass(case, key, with_addend):
 
     rows = lib.fva_conv_dgrad_stat_rows(C.byref(d))
     assert rows > 0
-    part = torch.full((lib.fva_bn_partial_rows(rows) if rows > 2048 else rows, 2, Cin), float('nan'), device=DEV)
+    part = torch.full((lib.fva_bn_partial_rows(rows), 2, Cin), float('nan'), device=DEV)
     fs = _lib.BnBwdFuse(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr())
     dx1 = torch.empty_like(dx0)
     _lib.call('fva_conv_dgrad_bnstats', C.byref(d), C.c_void_p(dyptr), ops._p(wd), ops._p(dx1), ops._p(add), C.byref(fs), ops._stream())
@@ -83,7 +83,7 @@ def test_dgrad_bnstats_equals_reduce_pass(case, key, with_addend):
         return dg, db, coef
     dg1, db1, coef1 = finalize(part, rows)
     nb = lib.fva_bn_bwd_blocks(ops._code(dtype), M, Cin)
-    part0 = torch.empty((nb, 2, Cin), device=DEV)
+    part0 = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cin), device=DEV)
     _lib.call('fva_bn_silu_bwd_reduce', ops._code(dtype), ops._p(dx0), ops._p(y), ops._p(scale), ops._p(shift), ops._p(mean), ops._p(rstd),
               ops._p(part0), nb, M, Cin, ops._stream())
     dg0, db0, coef0 = finalize(part0, nb)

@@ -98,6 +98,68 @@ def wgrad():
               f'(max {epi.max():.2f}) us | start spread {rel[:, 0].max():.2f} us')
 
 
+def pw():
+    """1x1 layers on igemm_kernel (FVA_STAMP_IGEMM=1): forward with statistics; dgrad plain, with addend, with addend + fused
+    BatchNorm-backward statistics.  Phases per block: setup (pointers, prefetch issue) / first k-tile wait / rest of the k loop /
+    accumulators -> LDS (+ forward statistics) / store loop."""
+    lib = _lib.load()
+    dev, dtype = 'cuda:0', torch.bfloat16
+    NS = 16384
+    stamps = torch.zeros(NS * 8, dtype=torch.int64, device=dev)
+    for (B, Cin, Cout, H) in [(32, 256, 128, 80), (32, 512, 256, 40), (32, 1024, 512, 20), (32, 128, 64, 160)]:
+        g = torch.Generator().manual_seed(0)
+        M = B * H * H
+        x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev).to(dtype)
+        dyh = torch.randn(B, H + 2, H + 2, Cout, generator=g).to(dev).to(dtype)
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(dev)
+        d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, 1, 1, 1, 1)
+        wf, wd = ops.packed_weights(w, d, dtype, cache=False)
+        y = torch.empty(M, Cout, device=dev, dtype=dtype)
+        nblk = lib.fva_conv_stat_blocks(C.byref(d))
+        stats = torch.zeros(lib.fva_bn_partial_rows(nblk), 2, Cout, device=dev)
+        dx = torch.empty(M, Cin, device=dev, dtype=dtype)
+        add = torch.randn(M, Cin, generator=g).to(dev).to(dtype)
+        yprod = torch.randn(M, Cin, generator=g).to(dev).to(dtype)
+        coef = [torch.rand(Cin, device=dev) + 0.5 for _ in range(4)]
+        rows = lib.fva_conv_dgrad_stat_rows(C.byref(d))
+        part = torch.empty(lib.fva_bn_partial_rows(rows), 2, Cin, device=dev)
+        fs = _lib.BnBwdFuse(yprod.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr())
+        st = ops._stream()
+        cases = [
+            ('fwd+stats', (Cin + Cout) * 2, lambda: _lib.call('fva_conv_fwd', C.byref(d), ops._p(x), ops._p(wf), ops._p(y), ops._p(stats), st)),
+            ('dgrad plain', (Cin + Cout) * 2, lambda: _lib.call('fva_conv_dgrad', C.byref(d), ops._p(dyh), ops._p(wd), ops._p(dx), C.c_void_p(0), st)),
+            ('dgrad +addend', (2 * Cin + Cout) * 2, lambda: _lib.call('fva_conv_dgrad', C.byref(d), ops._p(dyh), ops._p(wd), ops._p(dx), ops._p(add), st)),
+            ('dgrad +addend +bnb', (3 * Cin + Cout) * 2, lambda: _lib.call('fva_conv_dgrad_bnstats', C.byref(d), ops._p(dyh), ops._p(wd), ops._p(dx), ops._p(add), C.byref(fs), st)),
+        ]
+        for name, bpp, run in cases:
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            stamps.zero_()
+            _lib.call('fva_conv_debug_stamps', ops._p(stamps), NS)
+            run()
+            torch.cuda.synchronize()
+            _lib.call('fva_conv_debug_stamps', C.c_void_p(0), 0)
+            s = stamps.cpu().numpy().reshape(-1, 8)[:, :6]
+            s = s[s[:, 5] > 0]
+            rel = (s - s[:, 0].min()) / 100.0
+            ph = np.diff(rel, axis=1)
+            med = np.median(ph, axis=0)
+            starts = np.sort(rel[:, 0])
+            print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic | {len(s)} blocks stamped, last exit {rel[:, 5].max():.1f} us | '
+                  f'medians: setup {med[0]:.2f} first-tile wait {med[1]:.2f} k-loop {med[2]:.2f} to-LDS {med[3]:.2f} store {med[4]:.2f} = {np.median(rel[:, 5] - rel[:, 0]):.2f} us/block | '
+                  f'block starts at 25/50/75 %: {starts[len(starts) // 4]:.1f} {starts[len(starts) // 2]:.1f} {starts[3 * len(starts) // 4]:.1f}', flush=True)
+
+
 if __name__ == '__main__':
-    main()
-    wgrad()
+    if len(sys.argv) > 1 and sys.argv[1] == 'pw':
+        pw()
+    else:
+        main()
+        wgrad()
