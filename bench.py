@@ -406,9 +406,11 @@ def main():
     with (timer if timer is not None else contextlib.nullcontext()) as kt:
         t0 = time.perf_counter()
         step_marks[0].record()
+        host_marks = [t0]
         for i in range(args.steps):
             loss = step()
             step_marks[i + 1].record()
+            host_marks.append(time.perf_counter())
         host_s = time.perf_counter() - t0          # time the host needed to ISSUE the steps (no sync inside a step)
         fence()
         elapsed = time.perf_counter() - t0
@@ -503,6 +505,7 @@ def main():
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE_640 * (args.size / 640.0) ** 2 * args.batch / 1e3 / (ms_step * 1e-3), 2),
             'loss': round(final_loss, 5), 'host_ms_per_step': round(host_s / args.steps * 1e3, 3),
             'step_ms': [round(step_marks[i].elapsed_time(step_marks[i + 1]), 2) for i in range(args.steps)],
+            'host_issue_ms': [round((host_marks[i + 1] - host_marks[i]) * 1e3, 2) for i in range(args.steps)],
             'settle_windows_ms_per_step': settle_log,
             'gc_passes_in_timed_region': [g for g in gc_log if g[1] >= 1.0] or len(gc_log),
         }

@@ -348,32 +348,36 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dc
     const int Ct = Cup + Cskip, cu = Cup / EPC, cs = Cskip / EPC;
     const int64_t n_up = (int64_t)B * hh * ww * cu, n_sk = (int64_t)B * 4 * hh * ww * cs;
     const int uoff = up_first ? 0 : Cskip, soff = up_first ? Cup : 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_up + n_sk; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_up) {
-            const int cc = (int)(i % cu);
-            const int64_t pix = i / cu;
-            const int x = (int)(pix % ww), y = (int)((pix / ww) % hh), b = (int)(pix / ((int64_t)ww * hh));
+    // 32-bit item arithmetic (the host checks the item count): 64-bit divisions cost more than the 16-byte copy they address
+    const uint32_t total = (uint32_t)(n_up + n_sk), nu = (uint32_t)n_up;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < nu) {
+            const uint32_t pix = i / (uint32_t)cu, cc = i - pix * (uint32_t)cu;
+            const uint32_t row = pix / (uint32_t)ww, x = pix - row * (uint32_t)ww;        // row = b * hh + y
+            const uint32_t b = row / (uint32_t)hh, y = row - b * (uint32_t)hh;
             float acc[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+            Vec16<T> v[4];
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int64_t sp = ((int64_t)b * 2 * hh + 2 * y + dy) * (2 * ww) + 2 * x + dx;
-                    const Vec16<T> v = *(const Vec16<T>*)(dcat + sp * Ct + uoff + cc * EPC);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[e] += v.get(e);
+                    v[dy * 2 + dx] = *(const Vec16<T>*)(dcat + sp * Ct + uoff + cc * EPC);
                 }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += v[q].get(e);
             Vec16<T> o;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.set(e, acc[e]);
-            *(Vec16<T>*)(dup + pix * Cup + cc * EPC) = o;
+            *(Vec16<T>*)(dup + (int64_t)pix * Cup + cc * EPC) = o;
         } else {
-            const int64_t j = i - n_up;
-            const int cc = (int)(j % cs);
-            const int64_t pix = j / cs;
-            *(Vec16<T>*)(dskip + pix * Cskip + cc * EPC) = *(const Vec16<T>*)(dcat + pix * Ct + soff + cc * EPC);
+            const uint32_t j = i - nu;
+            const uint32_t pix = j / (uint32_t)cs, cc = j - pix * (uint32_t)cs;
+            *(Vec16<T>*)(dskip + (int64_t)pix * Cskip + cc * EPC) = *(const Vec16<T>*)(dcat + (int64_t)pix * Ct + soff + cc * EPC);
         }
     }
 }
@@ -589,6 +593,7 @@ int fva_upsample2_concat_bwd(int dtype, const void* dcat, void* dup, void* dskip
     if (!dcat || !dup || !dskip) return fva_fail(FVA_ERR_ARG, "fva_upsample2_concat_bwd: null pointer");
     const int epc = dtype == FVA_BF16 ? 8 : 4;
     const int64_t items = (int64_t)B * h * w * (Cup / epc) + (int64_t)B * 4 * h * w * (Cskip / epc);
+    if (items >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_upsample2_concat_bwd: tensor too large");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(upcat_bwd_kernel<bf16_t>, dim3(stream_grid(items)), dim3(256), 0, s, (const bf16_t*)dcat, (bf16_t*)dup,

@@ -52,7 +52,6 @@ struct IgemmParams {
     int bnb_row0, bnb_C;
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
-    int skew;            // experiment: blocks of the second residency slot start half a tile period late
 };
 
 // coefficients of eight (bf16 chunk) consecutive channels for the fused BatchNorm-backward statistics
@@ -71,15 +70,17 @@ __device__ __forceinline__ void bnb_load(const IgemmParams& p, int n, BnbCoef& k
 // The same coefficients staged in LDS once per tile, [4][BN] floats indexed by the tile column: read from global memory in the
 // epilogue, the 32 dependent loads per thread sat in front of the statistics arithmetic (1-2 us per tile, tools/tile_timing.py pw).
 template <int BN, int NT>
+__device__ __forceinline__ float bnb_coef_at(const IgemmParams& p, int i, int n0) {   // table entry i of [4][BN]
+    const int which = i / BN, col = i - which * BN;
+    int c = n0 + col;
+    c = c < p.N ? c : p.N - 1;
+    c = c >= p.bnb_C ? c - p.bnb_C : c;
+    const float* src = which == 0 ? p.bnb_scale : which == 1 ? p.bnb_shift : which == 2 ? p.bnb_mean : p.bnb_rstd;
+    return src[c];
+}
+template <int BN, int NT>
 __device__ __forceinline__ void bnb_fill_lds(const IgemmParams& p, float* tab, int tid, int n0) {
-    for (int i = tid; i < 4 * BN; i += NT) {
-        const int which = i / BN, col = i - which * BN;
-        int c = n0 + col;
-        c = c < p.N ? c : p.N - 1;
-        c = c >= p.bnb_C ? c - p.bnb_C : c;
-        const float* src = which == 0 ? p.bnb_scale : which == 1 ? p.bnb_shift : which == 2 ? p.bnb_mean : p.bnb_rstd;
-        tab[i] = src[c];
-    }
+    for (int i = tid; i < 4 * BN; i += NT) tab[i] = bnb_coef_at<BN, NT>(p, i, n0);
 }
 template <int BN>
 __device__ __forceinline__ void bnb_load_lds(const float* tab, int col, BnbCoef& k) {
@@ -259,13 +260,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WN, wc = w % WN;
-    auto stamp = [&](int i) {   // 0 entry, 1 pointers / prefetches issued, 2 first k-tile landed, 3 k loop done, 4 tile staged in LDS, 5 exit
+    auto stamp = [&](int i) {   // 0 entry, 6 source rows / k table ready, 7 epilogue operands requested, 1 first DMA issued, 2 first k-tile landed, 3 k loop done, 4 tile staged in LDS, 5 exit
         if (p.stamps && tid == 0 && (int)blockIdx.x < p.stamp_rows) p.stamps[(int64_t)blockIdx.x * 8 + i] = wall_clock64();
     };
     stamp(0);
-    if (p.skew && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     // XCD-aware block order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles.
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -307,7 +305,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     constexpr int COEF_BYTES = (EPI == EPI_BNB && IS_BF16 && BN >= 128) ? 4 * BN * 4 : 0;   // bnb_fill_lds (the 256x64 tile has no LDS to spare)
     float* coef_tab = (float*)(smem + NSTAGE * STAGE);   // EPI_BNB: [4][BN] floats, see bnb_fill_lds
     int* ktab = (int*)(smem + NSTAGE * STAGE + COEF_BYTES);
-    if constexpr (COEF_BYTES > 0) bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);
+    // the table's values are fetched now and written to LDS only after the first DMA has been issued: a store right here would
+    // put a global round trip in front of everything else the block has to set up
+    constexpr int COEF_PER_THREAD = COEF_BYTES > 0 ? 4 * BN / NT : 0;
+    float coef_v[COEF_PER_THREAD > 0 ? COEF_PER_THREAD : 1];
+    if constexpr (COEF_BYTES > 0) {
+#pragma unroll
+        for (int j = 0; j < COEF_PER_THREAD; ++j) coef_v[j] = bnb_coef_at<BN, NT>(p, tid + j * NT, n0);
+    }
     if constexpr (USE_KTAB) {
         const int nent = p.halfrow ? 2 * p.ktiles : p.ktiles;
         for (int e = tid; e < nent; e += NT) {
@@ -324,6 +329,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
         __syncthreads();
     }
+    stamp(6);
     int ld_tap = 0, ld_kk = 0;  // running (tap, k-slice) of the next tile to fetch (thin tile only)
     auto load_tile = [&](int kt, int stage) {
         char* sA = smem + stage * STAGE;
@@ -403,6 +409,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     // finished reading (counted vmcnt: LDS-DMA retires in issue order).
     static_assert(NSTAGE == 2, "the loop below is written for two stages");
     constexpr int LPT = A_ITERS + B_ITERS;  // DMA instructions per wave and tile
+    if constexpr (COEF_BYTES > 0) {
+        // before the first LDS-DMA (hipcc drains vmcnt in front of an LDS access once one is in flight); the values were requested
+        // ahead of the epilogue operands, so the wait covers loads that have long returned.  Read in the epilogue, behind the barriers.
+#pragma unroll
+        for (int j = 0; j < COEF_PER_THREAD; ++j) coef_tab[tid + j * NT] = coef_v[j];
+    }
+    stamp(7);
     load_tile(0, 0);
     if (p.ktiles > 1) load_tile(1, 1);
     int st_cur = 0;
@@ -606,7 +619,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             // thin tile (its two stages are exactly half a CU's LDS): the coefficient table goes behind the staged tile now that the
             // ring is free -- one global load per thread under the transposition instead of 32 dependent ones in the store loop
             coef_tab = (float*)(smem + BM * PITCH);
-            bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);
+            static_assert(4 * BN <= NT || EPI != EPI_BNB || COEF_BYTES > 0, "one table entry per thread");
+            if (tid < 4 * BN) coef_v[0] = bnb_coef_at<BN, NT>(p, tid, n0);
         }
         foreach_acc(acc, lane, [&](int row, int col, int, float v) {
             if constexpr (EPI == EPI_BNACT) {
@@ -615,6 +629,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             }
             *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
         });
+        if constexpr (EPI == EPI_BNB && COEF_BYTES == 0) {
+            if (tid < 4 * BN) coef_tab[tid] = coef_v[0];
+        }
         __syncthreads();
         stamp(4);
         store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr,
@@ -631,8 +648,6 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     static const bool stamp_tiles = [] { const char* e = getenv("FVA_STAMP_IGEMM"); return e && atoi(e) != 0; }();   // tools/tile_timing.py pw
     q.stamps = stamp_tiles ? fva_debug_stamps_ptr() : nullptr;
     q.stamp_rows = stamp_tiles ? fva_debug_stamps_rows() : 0;
-    static const int skew = [] { const char* e = getenv("FVA_SKEW"); return e ? atoi(e) : 0; }();
-    q.skew = skew;
     // stages (+ k-tile offset table, wide tiles: 8 bytes per k-tile -- or per half k-tile in half-row mode --, at least 4 KiB; a fully
     // connected layer seen as a 1x1 convolution reduces over 25088 channels = 784 fp32 k-tiles)
     constexpr int KTAB_MAX = 16384;

@@ -7,20 +7,38 @@
 
 namespace {
 
+// dY (halo, Npad channels, zero beyond N and on the border) = g * dhead (dense fp32 rows of N = 255 floats: not 16-byte aligned).
+// One thread per 8 output channels: eight 4-byte loads (a wave covers whole cache lines of the row), one 16- or 32-byte store.
 template <typename T>
 __global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restrict__ dhead, const float* __restrict__ gscale,
                                                            T* __restrict__ dy, int B, int H, int W, int N, int Npad) {
-    const int Hp = H + 2, Wp = W + 2;
-    const int64_t total = (int64_t)B * Hp * Wp * Npad;
+    const uint32_t Hp = H + 2, Wp = W + 2, cpp = Npad / 8;
+    const uint32_t total = (uint32_t)B * Hp * Wp * cpp;
     const float g = gscale ? *gscale : 1.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i % Npad);
-        const int64_t pix = i / Npad;
-        const int xp = (int)(pix % Wp), yp = (int)((pix / Wp) % Hp), b = (int)(pix / ((int64_t)Wp * Hp));
-        const int y = yp - 1, x = xp - 1;
-        float v = 0.f;
-        if (n < N && y >= 0 && y < H && x >= 0 && x < W) v = g * dhead[(((int64_t)b * H + y) * W + x) * N + n];
-        dy[i] = from_f<T>(v);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t pix = i / cpp, cc = i - pix * cpp;
+        const uint32_t row = pix / Wp, xp = pix - row * Wp;
+        const uint32_t b = row / Hp, yp = row - b * Hp;
+        const int y = (int)yp - 1, x = (int)xp - 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float* src = dhead + (((int64_t)b * H + y) * W + x) * N + cc * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((int)(cc * 8 + e) < N) v[e] = g * src[e];
+        }
+        T* dst = dy + (int64_t)i * 8;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *(bf16x8*)dst = o;
+        } else {
+            *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
     }
 }
 
@@ -63,7 +81,8 @@ extern "C" int fva_head_bwd_prepare(int dtype, const float* dhead, const float* 
     if (!dhead || !dy || !dbias || !workspace) return fva_fail(FVA_ERR_ARG, "fva_head_bwd_prepare: null pointer");
     if (Npad < N || Npad % 8) return fva_fail(FVA_ERR_ARG, "fva_head_bwd_prepare: bad Npad %d for N %d", Npad, N);
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * (H + 2) * (W + 2) * Npad;
+    const int64_t total = (int64_t)B * (H + 2) * (W + 2) * (Npad / 8);   // items of 8 channels
+    if (total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_head_bwd_prepare: tensor too large");
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     if (dtype == FVA_BF16)

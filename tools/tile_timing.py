@@ -146,14 +146,19 @@ def pw():
             run()
             torch.cuda.synchronize()
             _lib.call('fva_conv_debug_stamps', C.c_void_p(0), 0)
-            s = stamps.cpu().numpy().reshape(-1, 8)[:, :6]
-            s = s[s[:, 5] > 0]
+            s8 = stamps.cpu().numpy().reshape(-1, 8)
+            s8 = s8[s8[:, 5] > 0]
+            s = s8[:, :6]
+            if not len(s):
+                print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic (no stamps: run with FVA_STAMP_IGEMM=1)', flush=True)
+                continue
             rel = (s - s[:, 0].min()) / 100.0
             ph = np.diff(rel, axis=1)
             med = np.median(ph, axis=0)
             starts = np.sort(rel[:, 0])
             print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic | {len(s)} blocks stamped, last exit {rel[:, 5].max():.1f} us | '
                   f'medians: setup {med[0]:.2f} first-tile wait {med[1]:.2f} k-loop {med[2]:.2f} to-LDS {med[3]:.2f} store {med[4]:.2f} = {np.median(rel[:, 5] - rel[:, 0]):.2f} us/block | '
+                  f'setup split: rows+ktab {np.median(s8[:, 6] - s8[:, 0]) / 100:.2f} operand requests {np.median(s8[:, 7] - s8[:, 6]) / 100:.2f} DMA issue {np.median(s8[:, 1] - s8[:, 7]) / 100:.2f} | '
                   f'block starts at 25/50/75 %: {starts[len(starts) // 4]:.1f} {starts[len(starts) // 2]:.1f} {starts[3 * len(starts) // 4]:.1f}', flush=True)
 
 
