@@ -230,7 +230,7 @@ def main():
         lib_surface = args.surface == 'lib'
         if lib_surface:
             crit.data_parallel()
-        reducer = parallel.GradientReducer(net.parameters(), average=not lib_surface, bucket_dtype=torch.bfloat16)
+        reducer = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20, average=not lib_surface, bucket_dtype=torch.bfloat16)
 
     images, targets = synthetic_batch(args.batch, args.size, rank=rank)     # per-rank shard of the global batch (weak scaling)
     images, targets = images.to(dev), targets.to(dev)

@@ -121,6 +121,7 @@ PROTOTYPES = {
     'fva_iou_batch': (_I, [_I, _I, _I, _P, _P, _P, _L, _L, _F, _P]),
     'fva_adam_step': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
     'fva_adam_step_dev': (_I, [_P, _P, _I, _L, _P, _F, _F, _F, _F, _P, _F, _P]),
+    'fva_gather_cast': (_I, [_P, _I, _L, _P, _I, _P]),
     'fva_paste_resize_normalize': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'fva_paste_resize_u8': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'fva_colour_workspace': (_L, [_I]),

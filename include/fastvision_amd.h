@@ -422,6 +422,12 @@ int fva_adam_step(const void* const* ptrs, const int64_t* sizes, int32_t n, int6
 int fva_adam_step_dev(const void* const* ptrs, const int64_t* sizes, int32_t n, int64_t max_size, const float* lr_dev, float beta1,
                       float beta2, float eps, float weight_decay, double* state_dev, float grad_scale, void* stream);
 
+/* Gradient bucket fill for the data-parallel all-reduce (parallel.GradientReducer; the reference's nn.DataParallel gathers
+ * gradients tensor by tensor, demos/yolov3_u/train.py:85): dst[offs[t] + i] = src_t[i], converted to dst_dtype (FVA_F32 or
+ * FVA_BF16), for n fp32 source tensors in one launch.  table_dev: 3n int64 in device memory = source pointers | element counts |
+ * element offsets into dst; a null pointer or zero count skips the tensor.  max_size sizes the grid. */
+int fva_gather_cast(const int64_t* table_dev, int32_t n, int64_t max_size, void* dst, int dst_dtype, void* stream);
+
 /* ---- VGG blocks of the two-stage head's backbone (demos/faster_rcnn/models/vgg.py: Conv2d + bias -> ReLU,
  * MaxPool2d(2, 2); no BatchNorm) ---------------------------------------------------------------------------------------------
  * fva_conv_fwd_bias_act: z = act(conv(x) + bias[n]) straight into the halo buffer z (border zeroed), act 1 = ReLU, 2 = none;

@@ -467,20 +467,24 @@ def _rccl_worker(rank, world, port, out):
     images, tg = synthetic_batch(4, 128)
     images, tg = images.to(DEV), tg.to(DEV)
     res = {}
-    for mode in ('plain', 'reduced'):
+    for mode in ('plain', 'reduced', 'wire16'):
         net, crit = lib_model(), lib_loss()                                  # bf16 compute: the bench's kernels
         opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.937, 0.999), weight_decay=5e-4)
         red = None
-        if mode == 'reduced':
-            red = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20)
-            red.world = 2            # a one-rank group averages to the identity: forces the collectives to be ISSUED
-        for _ in range(2):
+        if mode != 'plain':
+            # world=2 on a one-rank group (which averages to the identity): forces the collectives to be ISSUED
+            red = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20, world=2,
+                                           bucket_dtype=torch.bfloat16 if mode == 'wire16' else None)
+        for it in range(1 if mode == 'wire16' else 2):
             opt.zero_grad()
             loss = crit(net(images), tg)
             loss.backward()
             if red is not None:
                 launched = red.next_launch
                 red.finish()
+            if mode == 'plain' and it == 0:
+                torch.cuda.synchronize()
+                res['first_grad'] = {k: p.grad.detach().cpu().clone() for k, p in list(net.named_parameters())[::17]}
             opt.step()
         torch.cuda.synchronize()
         res[mode] = {k: p.detach().cpu().clone() for k, p in list(net.named_parameters())[::17]}
@@ -505,6 +509,9 @@ def test_reducer_over_rccl_with_side_stream_single_rank():
     for k in res['plain']:
         assert torch.equal(res['plain'][k], res['reduced'][k]), k
         assert torch.equal(res['plain_grad'][k], res['reduced_grad'][k]), k
+    # bf16 on the wire: after ONE step the gradients are the plain run's first-step gradients rounded to bf16 (fva_gather_cast)
+    for k in res['first_grad']:
+        assert torch.equal(res['first_grad'][k].bfloat16().float(), res['wire16_grad'][k]), k
 
 
 def test_config2_fp32_full_size_vs_oracle():
