@@ -14,7 +14,7 @@ import sys
 CLASSES = {'conv_fwd': lambda n: ('igemm_kernel' in n and re.search(r'ELi0ELi\d+EEE', n)) or 'igemm8_kernelILi0' in n or 'igemm8_kernel<0' in n,
            'conv_dgrad': lambda n: ('igemm_kernel' in n and re.search(r'ELi[14]ELi\d+EEE', n)) or 'igemm8_kernelILi1' in n or 'igemm8_kernel<1' in n
                                    or 'igemm8_kernelILi4' in n or 'igemm8_kernel<4' in n,
-           'conv_wgrad': lambda n: 'wgrad_kernel' in n or 'wgrad8_kernel' in n or 'wgrad_reduce_kernel' in n}
+           'conv_wgrad': lambda n: 'wgrad_kernel' in n or 'wgrad8_kernel' in n or 'wgrad_reduce_kernel' in n or 'wgrad_reduce4_kernel' in n}
 
 
 def load(path, counter):

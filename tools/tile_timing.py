@@ -106,13 +106,16 @@ def pw():
     dev, dtype = 'cuda:0', torch.bfloat16
     NS = 16384
     stamps = torch.zeros(NS * 8, dtype=torch.int64, device=dev)
-    for (B, Cin, Cout, H) in [(32, 256, 128, 80), (32, 512, 256, 40), (32, 1024, 512, 20), (32, 128, 64, 160)]:
+    shapes = [(32, 256, 128, 80, 1), (32, 512, 256, 40, 1), (32, 1024, 512, 20, 1), (32, 128, 64, 160, 1)]
+    if len(sys.argv) > 2 and sys.argv[2] == 'thin':
+        shapes = [(32, 32, 64, 320, 3), (32, 64, 128, 160, 3), (32, 64, 32, 320, 1), (32, 128, 256, 80, 3)]
+    for (B, Cin, Cout, H, ks) in shapes:
         g = torch.Generator().manual_seed(0)
         M = B * H * H
         x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev).to(dtype)
         dyh = torch.randn(B, H + 2, H + 2, Cout, generator=g).to(dev).to(dtype)
-        w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(dev)
-        d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, 1, 1, 1, 1)
+        w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).to(dev)
+        d = _lib.ConvDesc(ops._code(dtype), B, H, H, Cin, Cout, ks, 1, 1, 1)
         wf, wd = ops.packed_weights(w, d, dtype, cache=False)
         y = torch.empty(M, Cout, device=dev, dtype=dtype)
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
@@ -156,7 +159,7 @@ def pw():
             ph = np.diff(rel, axis=1)
             med = np.median(ph, axis=0)
             starts = np.sort(rel[:, 0])
-            print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic | {len(s)} blocks stamped, last exit {rel[:, 5].max():.1f} us | '
+            print(f'{Cin}->{Cout} k{ks} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic, {2.0 * M * Cin * Cout * ks * ks / us / 1e6:.0f} TF | {len(s)} blocks stamped, last exit {rel[:, 5].max():.1f} us | '
                   f'medians: setup {med[0]:.2f} first-tile wait {med[1]:.2f} k-loop {med[2]:.2f} to-LDS {med[3]:.2f} store {med[4]:.2f} = {np.median(rel[:, 5] - rel[:, 0]):.2f} us/block | '
                   f'setup split: rows+ktab {np.median(s8[:, 6] - s8[:, 0]) / 100:.2f} operand requests {np.median(s8[:, 7] - s8[:, 6]) / 100:.2f} DMA issue {np.median(s8[:, 1] - s8[:, 7]) / 100:.2f} | '
                   f'block starts at 25/50/75 %: {starts[len(starts) // 4]:.1f} {starts[len(starts) // 2]:.1f} {starts[3 * len(starts) // 4]:.1f}', flush=True)
