@@ -144,6 +144,8 @@ def pw():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
+            outbuf = y if name.startswith('fwd') else dx
+            chk = f'checksum {outbuf.float().sum().item():.6e} {outbuf.float().abs().sum().item():.6e}' + (f' part {part[:rows].double().sum().item():.9e}' if 'bnb' in name else '')
             stamps.zero_()
             _lib.call('fva_conv_debug_stamps', ops._p(stamps), NS)
             run()
@@ -153,7 +155,7 @@ def pw():
             s8 = s8[s8[:, 5] > 0]
             s = s8[:, :6]
             if not len(s):
-                print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic (no stamps: run with FVA_STAMP_IGEMM=1)', flush=True)
+                print(f'{Cin}->{Cout} @{H} {name}: launch {us:.1f} us = {M * bpp / us / 1e6:.2f} TB/s algorithmic, {2.0 * M * Cin * Cout * ks * ks / us / 1e6:.0f} TF | {chk}', flush=True)
                 continue
             rel = (s - s[:, 0].min()) / 100.0
             ph = np.diff(rel, axis=1)
