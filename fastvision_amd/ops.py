@@ -207,16 +207,19 @@ class _PackRegistry:
 _registry = _PackRegistry()
 
 
-def packed_weights(weight, desc, dtype, cache=True):
+def packed_weights(weight, desc, dtype, cache=True, owner=None):
     """(w_fwd, w_dgrad) in the MFMA operand layouts.  The pair is cached ON the parameter object and re-packed
-    only when its autograd version counter (bumped by every in-place update, incl. FusedAdam) or data moved."""
-    key = (weight._version, weight.data_ptr(), desc.dtype)
-    hit = getattr(weight, '_fva_packed', None) if cache else None
+    only when its autograd version counter (bumped by every in-place update, incl. FusedAdam) or data moved.
+    ``owner``: the parameter that ``weight`` is a same-memory view of (an nn.Linear weight seen as a 1x1 filter): the cache and
+    the one-launch re-pack registry then hang on the parameter."""
+    holder = weight if owner is None else owner
+    key = (holder._version, weight.data_ptr(), desc.dtype)
+    hit = getattr(holder, '_fva_packed', None) if cache else None
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
-    if hit is not None and hit[0][1:] == key[1:] and isinstance(weight, torch.nn.Parameter):
-        _registry.repack_all(weight.device)            # stale registered parameter: refresh every layer in one launch
-        hit = weight._fva_packed
+    if hit is not None and hit[0][1:] == key[1:] and isinstance(holder, torch.nn.Parameter):
+        _registry.repack_all(holder.device)            # stale registered parameter: refresh every layer in one launch
+        hit = holder._fva_packed
         if hit[0] == key:
             return hit[1], hit[2]
     lib = _lib.load()
@@ -224,9 +227,9 @@ def packed_weights(weight, desc, dtype, cache=True):
     wd = torch.empty(lib.fva_conv_packed_elems(C.byref(desc), 1), dtype=dtype, device=weight.device)
     _lib.call('fva_conv_pack_weights', C.byref(desc), _p(weight), _p(wf), _p(wd), _stream())
     if cache:
-        weight._fva_packed = (key, wf, wd)
-        if isinstance(weight, torch.nn.Parameter):
-            _registry.add(weight, desc, wf, wd)
+        holder._fva_packed = (key, wf, wd)
+        if isinstance(holder, torch.nn.Parameter):
+            _registry.add(holder, desc, wf, wd)
     return wf, wd
 
 

@@ -107,7 +107,7 @@ def main(steps=None, warmup=3, cpu_baseline=True):
            'config': {'workload': f'Faster R-CNN (the reference demo: VGG16 stride-16 backbone + RPN + Fast head) train step {B}x3x{H}x{W} bf16, '
                                   f'{NC} classes, 128+128 RPN / 16+48 Fast samples per image, grad-norm clip + Nesterov SGD (BASELINE config 5)',
                       'global_batch': B, 'parallelism': 'dp1'},
-           'roofline': roofline, 'kernels': kernels, 'loss': round(float(loss), 4),
+           'roofline': roofline, 'kernels': kernels, 'loss': round(float(loss.detach()), 4),
            'note': 'conv / pool / RoIAlign / matchers / proposal layer / fully connected layers / losses on the HIP kernels; host-inclusive '
                    '(each step reads sample counts back like the reference)'}
     if cpu is not None:
