@@ -387,6 +387,9 @@ def main():
             KernelTimer(pool=calls_per_step * args.steps + 8, classes=[dom], stride=SAMPLE_STRIDE)
     fence()
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: where the time goes
+    for e in step_marks:             # torch creates the HIP event at the first record(): do that here, not between timed steps
+        e.record()                   # (event creation is a driver call; driver calls have stalled for 0.2-0.3 s right after another
+    fence()                          # GPU process on the box exited -- the one timed step of 180-310 ms seen twice in this round's runs)
     # Python's cyclic garbage collector: a generation-2 pass over everything this process has built (modules, the oracle's
     # imports, autograd graphs) stops the launching thread for 0.2-0.3 s -- ten steps' worth of queued GPU work runs dry.
     # Collect now, then freeze the survivors into the permanent generation so that later passes only look at new objects;
