@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, 'libfastvision_amd.so')
 SOURCES = ['errors.hip', 'conv_igemm.hip', 'conv_wgrad.hip', 'bn_act.hip', 'stem.hip', 'head.hip', 'loss.hip',
            'optim.hip', 'detect.hip', 'pipeline.hip', 'colour.hip', 'roi.hip', 'vgg.hip']
 # -ffp-contract=off: the matcher must reproduce the reference's fp32 op order bit for bit (no FMA fusion)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function'] + os.environ.get('FVA_EXTRA_FLAGS', '').split()   # experiments: e.g. -DFVA_NT_STORES=1 (use with --force)
 PER_FILE = {'colour.hip': ['-ffp-contract=off'], 'loss.hip': ['-ffp-contract=off'], 'detect.hip': ['-ffp-contract=off'], 'roi.hip': ['-ffp-contract=off']}
 
 

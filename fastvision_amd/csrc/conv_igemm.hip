@@ -128,6 +128,31 @@ __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
 }
 
 
+// The epilogue's output tile is written once and not read again by this launch: stored non-temporal it does not evict the input
+// rows that the nine taps re-read through L2 (an L2 hit arrives at 34 TB/s, a miss at 6-7: profiles/r02_dma_probe.md).  Same-box A/B
+// (bench.py, two runs each): 1041.4 / 1041.5 against 1033.3 / 1036.8 img/s, graph replay 31.8 against 32.1 ms; isolated launches of the
+// thin and 1x1 layers 4-20 % faster.  Non-temporal LOADS of the residual addend / the producer's y measured neutral (-DFVA_NT_LOADS=1).
+#ifndef FVA_NT_LOADS
+#define FVA_NT_LOADS 0
+#endif
+#ifndef FVA_NT_STORES
+#define FVA_NT_STORES 1
+#endif
+__device__ __forceinline__ bf16x8 ld_stream(const bf16_t* p) {
+#if FVA_NT_LOADS
+    return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load((const u32x4*)p));
+#else
+    return *(const bf16x8*)p;
+#endif
+}
+__device__ __forceinline__ void st_stream(bf16_t* p, bf16x8 v) {
+#if FVA_NT_STORES
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);
+#else
+    *(bf16x8*)p = v;
+#endif
+}
+
 // The block's transposed bf16 tile (LDS, row pitch PITCH bytes) -> global memory, 16 bytes per thread and step.  A thread keeps
 // its 16-byte column chunk over all steps (NT % CPR == 0).  The global operands of a GROUP of steps -- the residual addend, and
 // for EPI_BNB the producer's y -- are fetched first, all in flight together, and consumed afterwards: issued one per step behind
@@ -166,7 +191,7 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
                 for (int j = 0; j < GROUP; ++j) ad[j] = a_pre[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) ad[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi[j]);
+                for (int j = 0; j < GROUP; ++j) ad[j] = ld_stream((const bf16_t*)p.addend + oi[j]);
             }
         }
         if constexpr (EPI == EPI_BNB) {
@@ -175,7 +200,7 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
                 for (int j = 0; j < GROUP; ++j) yv[j] = y_pre[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) yv[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi[j]);
+                for (int j = 0; j < GROUP; ++j) yv[j] = ld_stream((const bf16_t*)p.bnb_y + oi[j]);
             }
         }
 #pragma unroll
@@ -187,7 +212,7 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
                 for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[j][e]);
             }
             if (ok[j]) {
-                *(bf16x8*)(out + oi[j]) = v;
+                st_stream(out + oi[j], v);
                 if constexpr (EPI == EPI_BNB) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -383,8 +408,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 }
                 oi = pixel * p.out_pitch + n;
             }
-            if constexpr (EPI == EPI_BNB) y_pre[j] = *(const bf16x8*)((const bf16_t*)p.bnb_y + oi);
-            if (p.addend != nullptr) a_pre[j] = *(const bf16x8*)((const bf16_t*)p.addend + oi);
+            if constexpr (EPI == EPI_BNB) y_pre[j] = ld_stream((const bf16_t*)p.bnb_y + oi);
+            if (p.addend != nullptr) a_pre[j] = ld_stream((const bf16_t*)p.addend + oi);
         }
     }
 
