@@ -24,6 +24,21 @@ __device__ __forceinline__ void wait_vmcnt_n() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// -DFVA_NT_SLAB=1 writes the partial tiles non-temporal (so that they do not evict the operand rows other blocks re-read).  Measured
+// (same box, two bench runs each): it LOSES -- wgrad class 8.5 -> 9.15 ms, 1022 -> 1017 img/s: the reduce kernel that follows reads
+// the slabs back, and finds them in cache only when they were written the ordinary way.  (The convolution epilogue's output tile is
+// the opposite case: conv_igemm.hip st_stream.)
+#ifndef FVA_NT_SLAB
+#define FVA_NT_SLAB 0
+#endif
+__device__ __forceinline__ void slab_store(float* p, float v) {
+#if FVA_NT_SLAB
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct WgradParams {
     const void* x;
     const void* dy;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             tap = tg;
             c = c0 + j;
         }
-        if (n < p.N && c < p.C && tap < p.ntaps) out[((int64_t)tap * p.N + n) * p.C + c] = v;
+        if (n < p.N && c < p.C && tap < p.ntaps) slab_store(out + ((int64_t)tap * p.N + n) * p.C + c, v);
     };
     if constexpr (IS_BF16) {
         const int r = lane & 15, g = lane >> 4;
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int n = n0 + wr * 128 + mi * 16 + g * 4 + jj;
-                    if (n < p.N) out[((int64_t)tap * p.N + n) * p.C + c] = acc[mi][ni][jj];
+                    if (n < p.N) slab_store(out + ((int64_t)tap * p.N + n) * p.C + c, acc[mi][ni][jj]);
                 }
             }
         }
