@@ -136,6 +136,28 @@ __device__ __forceinline__ bool halo_decode(const HaloIdx& h, uint32_t idx, int&
     return y >= 0 && y < h.H && x >= 0 && x < h.W;
 }
 
+// The apply passes read their dense inputs (y; dz and y) for the last time before those tensors go cold; read non-temporal they leave
+// the caches to what the pass WRITES, which the next convolution launches read.  Same-box A/B (bench.py, two runs each): 1053.6 / 1057.3
+// against 1048.4 / 1046.4 img/s.  -DFVA_NT_BN=0 switches back; -DFVA_NT_RES=1 also reads the residual that way (measured neutral, as were
+// non-temporal slab reads in the split-K reduce).
+#ifndef FVA_NT_BN
+#define FVA_NT_BN 1
+#endif
+#ifndef FVA_NT_RES
+#define FVA_NT_RES 0
+#endif
+template <typename T>
+__device__ __forceinline__ Vec16<T> ld_last(const T* p) {
+#if FVA_NT_BN
+    Vec16<T> r;
+    const u32x4 raw = __builtin_nontemporal_load((const u32x4*)p);
+    __builtin_memcpy(&r, &raw, 16);
+    return r;
+#else
+    return *(const Vec16<T>*)p;
+#endif
+}
+
 // One block per row of the padded output buffer (blockIdx.x = b * Hp + yp): no index division per chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
@@ -164,9 +186,13 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
         const int xx = xp - h.pad;
         Vec16<T> out;
         if (row_in && xx >= 0 && xx < h.W) {
-            const Vec16<T> v = *(const Vec16<T>*)(yrow + (int64_t)xx * h.C + cc * EPC);
+            const Vec16<T> v = ld_last<T>(yrow + (int64_t)xx * h.C + cc * EPC);
             Vec16<T> r;
+#if FVA_NT_RES
+            if (res) r = ld_last<T>(rrow + (int64_t)xx * h.C + cc * EPC);
+#else
             if (res) r = *(const Vec16<T>*)(rrow + (int64_t)xx * h.C + cc * EPC);
+#endif
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 float o = silu_f(v.get(e) * sc[e] + sh[e]);
@@ -294,8 +320,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         Vec16<T> out;
         if (row_in && xx >= 0 && xx < h.W) {
             const int64_t off = (m0 + xx) * h.C + cc * EPC;
-            const Vec16<T> g = *(const Vec16<T>*)(dz + off);
-            const Vec16<T> v = *(const Vec16<T>*)(y + off);
+            const Vec16<T> g = ld_last<T>(dz + off);
+            const Vec16<T> v = ld_last<T>(y + off);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float yv = v.get(e);
