@@ -106,7 +106,9 @@ int64_t fva_conv_streamk_timeouts(void);
 /* Diagnostic: while set (non-NULL), every block of an 8-phase convolution launch writes eight values to stamps[block * 8 ..]:
  * wall_clock64 (100 MHz) at block entry, first k-tile ready, k-loop done and exit, then the shader-clock cycle counter at the
  * same four points (cycles / wall time = the shader clock under load).  `rows` = capacity of the buffer in blocks (8 values
- * each): blocks beyond it do not stamp.  NULL switches the stamps off. */
+ * each): blocks beyond it do not stamp.  NULL switches the stamps off.  With FVA_STAMP_IGEMM=1 in the environment the 128x128 /
+ * 256x64 kernels stamp too, eight wall-clock values per block: entry, first DMA issued, first k-tile landed, k loop done, tile staged
+ * in LDS, exit, source rows ready, epilogue operands requested (tools/tile_timing.py pw). */
 int fva_conv_debug_stamps(void* stamps, int32_t rows);
 
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
