@@ -412,3 +412,34 @@ def test_stem_fused_passes_equal_unfused_path(monkeypatch):
     for name, a, b in zip(names, res['1'], res['0']):
         assert rel_err(a, b) < 2e-2, (name, rel_err(a, b))
     assert rel_err(res['1'][4], res['0'][4]) < 1e-4 and rel_err(res['1'][5], res['0'][5]) < 1e-4
+
+
+@pytest.mark.parametrize('wire', [torch.bfloat16, torch.float32])
+def test_gather_cast_fills_a_gradient_bucket(wire):
+    """fva_gather_cast (parallel.GradientReducer's bucket fill; the reference gathers gradients tensor by tensor inside
+    nn.DataParallel, demos/yolov3_u/train.py:85): n fp32 tensors -> one flat buffer at given element offsets, narrowed to the wire
+    dtype with round-to-nearest-even; odd sizes / offsets take the scalar path, a null pointer or a zero count skips the tensor."""
+    import ctypes as C
+    from fastvision_amd import _lib, ops
+    DEV = dev()
+    g = torch.Generator().manual_seed(5)
+    sizes = [4096, 255, 1, 32 * 3 * 3 * 3, 1024 * 512, 7, 64]
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += n
+    dst = torch.full((off,), float('nan'), dtype=wire, device=DEV)
+    ptrs = [t.data_ptr() for t in srcs]
+    ptrs[2] = 0                                   # skipped by pointer
+    cnt = list(sizes)
+    cnt[5] = 0                                    # skipped by count
+    table = torch.tensor(ptrs + cnt + offs, dtype=torch.int64).to(DEV)
+    _lib.call('fva_gather_cast', C.c_void_p(table.data_ptr()), len(sizes), max(sizes), C.c_void_p(dst.data_ptr()), ops._code(wire), ops._stream())
+    torch.cuda.synchronize()
+    for i, (t, o, n) in enumerate(zip(srcs, offs, sizes)):
+        got = dst[o:o + n]
+        if i in (2, 5):
+            assert torch.isnan(got.float()).all(), i
+        else:
+            assert torch.equal(got, t.to(wire)), i
