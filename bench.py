@@ -124,7 +124,7 @@ def dry_run(args):
                  in_channels=3, num_classes=80, training=True)
     parallel.broadcast_parameters(net)
     params = [p for p in net.parameters() if p.requires_grad]
-    reducer = parallel.GradientReducer(params, average=False, bucket_dtype=torch.bfloat16) if world > 1 else None
+    reducer = parallel.GradientReducer(params, average=False, bucket_dtype=torch.bfloat16 if args.wire == 'bf16' else None) if world > 1 else None
 
     def step():
         for p in params:
@@ -155,6 +155,7 @@ def dry_run(args):
                           'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'dry-run (no GPU, gloo, stand-in gradients)',
                           'dry_run': True, 'reduced_gradients_ok': ok, 'n_params': sum(p.numel() for p in params),
+                          'dp': reducer.stats() if reducer is not None else None,
                           'config': {'workload': 'launcher / rendezvous / gradient-bucket all-reduce only', 'parallelism': f'dp{world}'}}))
     if world > 1:
         dist.barrier()
@@ -177,6 +178,10 @@ def main():
     ap.add_argument('--model', default='yolov3', choices=['yolov3', 'faster_rcnn'],
                     help='faster_rcnn: the train step of the reference\'s Faster R-CNN demo at BASELINE config 5 (4x3x800x1333, one GPU)')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: launcher + rendezvous + gradient reduction over gloo only')
+    ap.add_argument('--wire', default='fp32', choices=['fp32', 'bf16'],
+                    help='dtype of the gradient buckets on the wire for --gpus N > 1: fp32 is what the reference\'s DataParallel reduces (default); '
+                         'bf16 halves the bytes over xGMI (recorded in config.grad_wire_dtype)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the Faster R-CNN (BASELINE config 5) block of the default one-GPU line')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
         sys.exit(spawn_ranks(args.gpus))
@@ -230,7 +235,8 @@ def main():
         lib_surface = args.surface == 'lib'
         if lib_surface:
             crit.data_parallel()
-        reducer = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20, average=not lib_surface, bucket_dtype=torch.bfloat16)
+        reducer = parallel.GradientReducer(net.parameters(), bucket_bytes=16 << 20, average=not lib_surface,
+                                           bucket_dtype=torch.bfloat16 if args.wire == 'bf16' else None)
 
     images, targets = synthetic_batch(args.batch, args.size, rank=rank)     # per-rank shard of the global batch (weak scaling)
     images, targets = images.to(dev), targets.to(dev)
@@ -308,7 +314,7 @@ def main():
             def arm():      # the roofline class bracketed by event-record nodes inside the captured sequence
                 fva_lib.call('fva_profile_classes', 1, 1)
                 fva_lib.call('fva_profile_start', calls_per_step + 8)
-            return GraphedTrainStep(net, loss_fn, opt, images, targets, warmup=1, on_capture=arm if spans else None)
+            return GraphedTrainStep(net, loss_fn, opt, images, targets, warmup=1, on_capture=arm if spans else None, side_stream=side_on)
 
         def window(fn, n=3):
             fence()
@@ -463,10 +469,17 @@ def main():
             roof_how = 'every forward launch of 3 eagerly issued steps right after the timed region (graph replays carry no events)'
     else:
         summ = kt.summary()
+    params_identical = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # every rank must hold the same parameters after the same steps (replicated model, reduced gradients): one checksum per rank
+        cs = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_identical = bool(lo.item() == hi.item())
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -526,8 +539,27 @@ def main():
         if args.shapes:
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):
                 print(f'{k}: launches {v[0]} ms_total {v[1]:.3f} tflops {v[2]:.1f}', file=sys.stderr)
+        if reducer is not None:
+            # what the driver needs to check that the collective backend really saw N ranks and that buckets overlapped backward
+            out['dp'] = reducer.stats()
+            out['dp']['parameters_identical_across_ranks'] = params_identical
+            out['config']['grad_wire_dtype'] = out['dp']['wire_dtype']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.size, args.batch)
+        if world == 1 and not args.no_secondary and not args.shapes and args.surface == 'lib' and args.dtype == 'bf16' and args.batch == 32 and args.size == 640:
+            # BASELINE config 5 (the reference's Faster R-CNN demo, demos/faster_rcnn/cfg/_fit.py:6-53) in the same driver-run line:
+            # its own step time, convolution classes and CPU baseline (tools/bench_faster.py = bench.py --model faster_rcnn)
+            try:
+                del net, opt, images, targets
+                gc.collect()
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import bench_faster
+                sec = bench_faster.main(steps=10, warmup=3, cpu_baseline=not args.no_cpu_baseline, emit=False)
+                out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'kernels',
+                                                         'loss', 'cpu_baseline') if k in sec}
+            except Exception as e:                                   # never lose the primary line to the secondary workload
+                out['secondary'] = {'error': f'{type(e).__name__}: {e}'}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

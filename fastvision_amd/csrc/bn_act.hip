@@ -158,17 +158,30 @@ __device__ __forceinline__ Vec16<T> ld_last(const T* p) {
 #endif
 }
 
-// One block per row of the padded output buffer (blockIdx.x = b * Hp + yp): no index division per chunk.
+// One block per row of the padded output buffer (blockIdx.x = b * Hp + yp): no index division per chunk.  A thread keeps U chunks
+// in flight per step (all loads of a step are issued before the first is used; masked chunks read a clamped address and store
+// zeros -- no branch around a load): at one chunk per step the passes ran 4.3 (backward) - 5.6 TB/s, latency- not bandwidth-bound
+// (PMC: 78 % of the wave cycles waiting, 10 % issuing).
+#ifndef FVA_BN_UNROLL
+#define FVA_BN_UNROLL 2      // measured 1 / 2 / 4 (tools/bench_bn.py, sum over the layer shapes): fwd 348 / 337 / 340 us, bwd 514 / 506 / 504 us
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const T* __restrict__ res,
                                                             int res_pad, T* __restrict__ z, const HaloIdx h) {
-    constexpr int EPC = Vec16<T>::N;
+    constexpr int EPC = Vec16<T>::N, U = FVA_BN_UNROLL;
     const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
     const int yy = yp - h.pad;
     const bool row_in = yy >= 0 && yy < h.H;
     const int row_chunks = h.Wp * h.cpp;
     T* zrow = z + (int64_t)blockIdx.x * row_chunks * EPC;
+    if (!row_in) {   // a border row: zeros (block-uniform branch)
+        Vec16<T> zero;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
+        for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = zero;
+        return;
+    }
     const T* yrow = y + ((int64_t)b * h.H + yy) * h.W * h.C;
     const int rW = h.W + 2 * res_pad;
     const T* rrow = res ? res + (((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + res_pad) * h.C : nullptr;
@@ -181,29 +194,37 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
         sc[e] = scale[cc * EPC + e];
         sh[e] = shift[cc * EPC + e];
     }
-    for (int i = threadIdx.x; i < row_chunks; i += 256) {
-        const int xp = i >> cshift;
-        const int xx = xp - h.pad;
-        Vec16<T> out;
-        if (row_in && xx >= 0 && xx < h.W) {
-            const Vec16<T> v = ld_last<T>(yrow + (int64_t)xx * h.C + cc * EPC);
-            Vec16<T> r;
+    const bool has_res = res != nullptr;
+    for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
+        Vec16<T> v[U], r[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            const int xx = (i >> cshift) - h.pad;
+            ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
+            const int64_t off = (int64_t)(ok[u] ? xx : 0) * h.C + cc * EPC;
+            v[u] = ld_last<T>(yrow + off);
+            if (has_res) {
 #if FVA_NT_RES
-            if (res) r = ld_last<T>(rrow + (int64_t)xx * h.C + cc * EPC);
+                r[u] = ld_last<T>(rrow + off);
 #else
-            if (res) r = *(const Vec16<T>*)(rrow + (int64_t)xx * h.C + cc * EPC);
+                r[u] = *(const Vec16<T>*)(rrow + off);
 #endif
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            Vec16<T> out;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                float o = silu_f(v.get(e) * sc[e] + sh[e]);
-                if (res) o += r.get(e);
-                out.set(e, o);
+                float o = silu_f(v[u].get(e) * sc[e] + sh[e]);
+                if (has_res) o += r[u].get(e);
+                out.set(e, ok[u] ? o : 0.f);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
+            if (i < row_chunks) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = out;
         }
-        *(Vec16<T>*)(zrow + (int64_t)i * EPC) = out;
     }
 }
 
@@ -294,12 +315,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h) {
-    constexpr int EPC = Vec16<T>::N;
+    constexpr int EPC = Vec16<T>::N, U = FVA_BN_UNROLL;
     const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
     const int yy = yp - h.pad;
     const bool row_in = yy >= 0 && yy < h.H;
     const int row_chunks = h.Wp * h.cpp;
     T* orow = dy + (int64_t)blockIdx.x * row_chunks * EPC;
+    if (!row_in) {
+        Vec16<T> zero;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
+        for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(orow + (int64_t)i * EPC) = zero;
+        return;
+    }
     const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);
     // lane-constant channel chunk (cpp divides 256): dY = a*dU + k1*y + k2 with k1 = coefB*rstd, k2 = coefC - k1*mean
@@ -314,25 +342,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k1[e] = coef[h.C + c] * rstd[c];
         k2[e] = coef[2 * h.C + c] - k1[e] * mean[c];
     }
-    for (int i = threadIdx.x; i < row_chunks; i += 256) {
-        const int xp = i >> cshift;
-        const int xx = xp - h.pad;
-        Vec16<T> out;
-        if (row_in && xx >= 0 && xx < h.W) {
-            const int64_t off = (m0 + xx) * h.C + cc * EPC;
-            const Vec16<T> g = ld_last<T>(dz + off);
-            const Vec16<T> v = ld_last<T>(y + off);
+    for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
+        Vec16<T> g[U], v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            const int xx = (i >> cshift) - h.pad;
+            ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
+            const int64_t off = (m0 + (ok[u] ? xx : 0)) * h.C + cc * EPC;
+            g[u] = ld_last<T>(dz + off);
+            v[u] = ld_last<T>(y + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            Vec16<T> out;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const float yv = v.get(e);
-                const float du = g.get(e) * silu_grad(yv * sc[e] + sh[e]);
-                out.set(e, ka[e] * du + k1[e] * yv + k2[e]);
+                const float yv = v[u].get(e);
+                const float du = g[u].get(e) * silu_grad(yv * sc[e] + sh[e]);
+                out.set(e, ok[u] ? ka[e] * du + k1[e] * yv + k2[e] : 0.f);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) out.set(e, 0.f);
+            if (i < row_chunks) *(Vec16<T>*)(orow + (int64_t)i * EPC) = out;
         }
-        *(Vec16<T>*)(orow + (int64_t)i * EPC) = out;
     }
 }
 
@@ -451,11 +484,14 @@ inline int stream_grid(int64_t items) {
 
 extern "C" {
 
-int fva_bn_finalize(float* part, int32_t nblocks, int64_t count, int32_t C, const float* gamma, const float* beta,
+int fva_bn_finalize(float* part, int32_t nblocks, int32_t partial_rows, int64_t count, int32_t C, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                     float* save_mean, float* save_rstd, float* scale, float* shift, void* stream) {
     if (!part || !gamma || !beta || !save_mean || !save_rstd || !scale || !shift || nblocks <= 0 || count <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_finalize: bad argument");
+    if (partial_rows < fva_bn_partial_rows(nblocks))
+        return fva_fail(FVA_ERR_WORKSPACE, "fva_bn_finalize: the table holds %d rows, %d rows of producers need fva_bn_partial_rows() = %d", partial_rows, nblocks,
+                        fva_bn_partial_rows(nblocks));
     const double* pre = nullptr;
     int pre_rows = 0;
     if (nblocks >= PRE_MIN) {
@@ -551,10 +587,13 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
     return FVA_OK;
 }
 
-int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int64_t M, int C, const float* gamma, const float* save_rstd,
+int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, int64_t M, int C, const float* gamma, const float* save_rstd,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
     if (!partial || !gamma || !save_rstd || !dgamma || !dbeta || !coef || nblocks <= 0 || M <= 0 || C <= 0)
         return fva_fail(FVA_ERR_ARG, "fva_bn_bwd_finalize: bad argument");
+    if (partial_rows < fva_bn_partial_rows(nblocks))
+        return fva_fail(FVA_ERR_WORKSPACE, "fva_bn_bwd_finalize: the table holds %d rows, %d rows of producers need fva_bn_partial_rows() = %d", partial_rows,
+                        nblocks, fva_bn_partial_rows(nblocks));
     // long tables (the fused dgrad epilogues write one row per 128- or 256-pixel block) are first folded in parallel, as in the
     // forward pass: C / 16 blocks walking 1600 rows of a C = 128 layer took 72 us, the two-level form takes 5 + 5 (the caller
     // allocated fva_bn_partial_rows(nblocks) rows: the doubles live behind the table)

@@ -10,8 +10,10 @@
 //
 // Replaces nn.Conv2d forward/backward-data as issued by ConvBlock3x3/ConvBlock1x1
 // (reference classfication/models/darknet53.py:5-9, 22-44) and the head conv (detection/head/yolov3head.py:50).
+#include <stddef.h>
 #include <stdlib.h>
 
+#include "bn_ticket.h"
 #include "common.h"
 
 namespace {
@@ -52,6 +54,9 @@ struct IgemmParams {
     int bnb_row0, bnb_C;
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
+    int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
+    FastDiv pt_div_tx, pt_div_img;  //   divisions by pt_tx and pt_tx * pt_ty
+    BnTicket tk;         // mode != 0: the statistics table (stats / bnb_part) is folded and finalised inside this launch (bn_ticket.h)
 };
 
 // coefficients of eight (bf16 chunk) consecutive channels for the fused BatchNorm-backward statistics
@@ -101,6 +106,7 @@ template <int BN, int NT, int CPR>
 __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, const float (&s1)[8], const float (&s2)[8], int tid, int mblk,
                                            int n0) {
     constexpr int G = NT / CPR;
+    static_assert(NT / 64 >= BN / 32, "one wave per 32-channel slice of the block's columns");
     const int cc = tid % CPR, grp = tid / CPR;
     __syncthreads();   // every thread is done reading the transposed tile
 #pragma unroll
@@ -109,15 +115,20 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
         red[(1 * G + grp) * BN + cc * 8 + e] = s2[e];
     }
     __syncthreads();
-    for (int i = tid; i < 2 * BN; i += NT) {
-        const int which = i / BN, col = i - which * BN;
+    // wave w owns the 32 columns n0 + 32 w ..: lanes 0-31 the first sum, lanes 32-63 the second (one 128-byte line each), stored
+    // write-through so that the launch can fold the table itself (bn_ticket.h)
+    const int w = tid >> 6, lane = tid & 63;
+    if (w < BN / 32) {
+        const int which = lane >> 5, col = w * 32 + (lane & 31);
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) t += red[(which * G + g) * BN + col];
         const int n = n0 + col;
-        if (n < p.N) {
-            const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-            p.bnb_part[(((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)] = t;
+        const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
+        if (n < p.N) st_agent(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C), t);
+        if (p.tk.mode && n0 + w * 32 < p.N) {
+            const int nw = n0 + w * 32, subw = nw >= p.bnb_C ? 1 : 0;
+            bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), (p.bnb_row0 + mblk) * per + subw, (nw - subw * p.bnb_C) >> 5, lane);
         }
     }
 }
@@ -157,11 +168,13 @@ __device__ __forceinline__ void st_stream(bf16_t* p, bf16x8 v) {
 // its 16-byte column chunk over all steps (NT % CPR == 0).  The global operands of a GROUP of steps -- the residual addend, and
 // for EPI_BNB the producer's y -- are fetched first, all in flight together, and consumed afterwards: issued one per step behind
 // the previous step's store, each load pays a full memory round trip (measured: +60 us on a 100 us dgrad launch).
-template <int EPI, int BM, int BN, int NT, int PITCH, typename OutPixel>
-__device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem, int tid, int m0, int n0, int mblk, OutPixel&& out_pixel,
+// row_pixel(r) = output pixel index of tile row r, or -1 when that row is not stored (beyond M, or outside the image for the patch tiles).
+template <int EPI, int BM, int BN, int NT, int PITCH, typename RowPixel>
+__device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem, int tid, int n0, int mblk, RowPixel&& row_pixel,
                                                 const bf16x8* y_pre = nullptr, const bf16x8* a_pre = nullptr, const float* coef_lds = nullptr) {
-    constexpr int CPR = BN / 8, ITERS = BM * CPR / NT, GROUP = 8, RSTEP = NT / CPR;
-    static_assert(NT % CPR == 0 && ITERS % GROUP == 0, "a thread keeps its column chunk; whole groups");
+    constexpr int CPR = BN / 8, ITERS = BM * CPR / NT, RSTEP = NT / CPR;
+    constexpr int GROUP = ITERS % 8 == 0 ? 8 : ITERS % 7 == 0 ? 7 : ITERS;   // 7: the 224-row tile (14 steps); 4: the 256 x 32 patch tile
+    static_assert(NT % CPR == 0 && ITERS % GROUP == 0 && GROUP <= 8, "a thread keeps its column chunk; whole groups");
     bf16_t* out = (bf16_t*)p.out;
     const int cc = tid % CPR, r0 = tid / CPR;
     const int n = n0 + cc * 8;
@@ -181,9 +194,9 @@ __device__ __forceinline__ void store_tile_bf16(const IgemmParams& p, char* smem
         bf16x8 ad[GROUP], yv[GROUP];
 #pragma unroll
         for (int j = 0; j < GROUP; ++j) {
-            const int m = m0 + r0 + (g * GROUP + j) * RSTEP;
-            ok[j] = col_ok && m < p.M;
-            oi[j] = ok[j] ? out_pixel(m) * p.out_pitch + n : 0;     // masked steps read element 0: no branch around a load
+            const int64_t pixel = row_pixel(r0 + (g * GROUP + j) * RSTEP);
+            ok[j] = col_ok && pixel >= 0;
+            oi[j] = ok[j] ? pixel * p.out_pitch + n : 0;            // masked steps read element 0: no branch around a load
         }
         if (has_add) {
             if (a_pre != nullptr) {
@@ -545,12 +558,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 }
             }
             __syncthreads();
-            if (tid < 2 * BN) {
-                const int which = tid / BN, col = tid - which * BN;
+            if (w < BN / 32) {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
+                const int which = lane >> 5, col = w * 32 + (lane & 31);
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
-                if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
+                if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
             }
             __syncthreads();
         }
@@ -624,15 +637,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     }
                 }
                 __syncthreads();
-                if (tid < 2 * BN) {
-                    const int which = tid / BN, col = tid - which * BN;
+                if (w < BN / 32) {
+                    const int which = lane >> 5, col = w * 32 + (lane & 31);
                     float t = 0.f;
 #pragma unroll
                     for (int k = 0; k < WMc; ++k) t += red[(which * WMc + k) * BN + col];
                     const int n = n0 + col;
-                    if (n < p.N) {
-                        const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-                        p.bnb_part[(((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)] = t;
+                    const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
+                    if (n < p.N) st_agent(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C), t);
+                    if (p.tk.mode && n0 + w * 32 < p.N) {
+                        const int nw = n0 + w * 32, subw = nw >= p.bnb_C ? 1 : 0;
+                        bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), (p.bnb_row0 + mblk) * per + subw, (nw - subw * p.bnb_C) >> 5, lane);
                     }
                 }
             }
@@ -659,8 +674,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
         __syncthreads();
         stamp(4);
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, m0, n0, mblk, out_pixel, EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr,
-                                                coef_tab);
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
+                                                EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr, coef_tab);
+    }
+    if constexpr (EPI == EPI_STATS) {
+        // the statistics table folds itself: this wave's row slice went out before the tile, so the drain in front of the ticket
+        // finds it long acknowledged
+        if (p.tk.mode && p.stats != nullptr && w < BN / 32 && n0 + w * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), mblk, (n0 >> 5) + w, lane);
     }
     stamp(5);
 }
@@ -690,6 +710,261 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
     FVA_LAUNCH_CHECK("igemm_kernel");
     return FVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Patch convolution: the thin 3x3 stride-1 layers (32 -> 64 at 320^2, 64 -> 128 at 160^2 and their data gradients, 64 -> 32 and
+// 128 -> 64: reduction channels C <= 128, outputs N <= 128, bf16).  The implicit-GEMM kernels above fetch every tap's A tile
+// separately: 9 x (256 pixels x 128 B) through L2 -> LDS for 256 output pixels, and with K this short nothing amortises it -- the
+// block-phase stamps (profiles/r02_tile_phases.md) put 43-75 % of a block's life into a k loop that runs at the L2 -> LDS rate
+// (17-20 TB/s chip-wide), four times slower than its MFMAs.  Here a block owns a PATCH of 8 x 32 output pixels of one image: the
+// (8+2) x (32+2) input pixels it needs are staged ONCE (LDS-DMA, pixel-major rows of one 64- or 32-channel slice, XOR-swizzled on
+// the source side), and the nine taps are nine shifted fragment reads of that image: 1.33 instead of 9 input bytes per output
+// pixel and channel.  The weights of one (tap, channel slice) are a [N][slice] matrix: all nine resident when they fit 36 KiB
+// (C x N <= 2048), else streamed through two LDS slots one step ahead of the MFMAs.  4 waves, each 2 patch rows (64 pixels =
+// four 16-pixel A tiles) x all N columns; epilogues, statistics and the store loop are the implicit-GEMM kernel's
+// (EPI_STATS / EPI_PLAIN / EPI_BNB, tile row r <-> patch pixel (r / 32, r % 32)).  Same products in the same order per output as
+// igemm_kernel with tap-major k order -- but slice-major there (ktaps), so results agree to fp32 summation order, not bit for bit.
+template <int CS, int BN, int NSL, int EPI>
+__global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;             // 340 patch pixels
+    constexpr int PIXB = CS * 2;                                                   // bytes of a pixel row in LDS: 128 / 64
+    constexpr int CPP = PIXB / 16;                                                 // 16-byte chunks per pixel: 8 / 4
+    constexpr int PPI = 1024 / PIXB;                                               // pixels per LDS-DMA instruction: 8 / 16
+    constexpr int PATCH_INSTR = (NPIX + PPI - 1) / PPI, PATCH_BYTES = PATCH_INSTR * 1024;
+    constexpr int WSTEP_BYTES = BN * PIXB, WPW = WSTEP_BYTES / 1024 / 4;           // one (tap, slice) matrix; its DMA instructions per wave
+    static_assert(WSTEP_BYTES % 4096 == 0, "whole DMA instructions per wave");
+    constexpr int STEPS = 9 * NSL;
+    constexpr bool RESIDENT = NSL == 1 && 9 * WSTEP_BYTES <= 36 * 1024;
+    constexpr int WBUF_BYTES = (RESIDENT ? 9 : 2) * WSTEP_BYTES;
+    constexpr int BM = 256, NT = 256, NTILE = BN / 16, KS = CS / 32;
+    constexpr int PITCH = BN * 2 + 16, TILE_BYTES = BM * PITCH;
+    constexpr int COEF0 = TILE_BYTES > PATCH_BYTES + WBUF_BYTES ? TILE_BYTES : PATCH_BYTES + WBUF_BYTES;   // BNB coefficient table: clear of both uses
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    char* const wbuf = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int b = (int)fd_div((uint32_t)tile, p.pt_div_img);
+    const int trem = tile - b * (p.pt_tx * p.pt_ty);
+    const int ty = (int)fd_div((uint32_t)trem, p.pt_div_tx), tx = trem - ty * p.pt_tx;
+    const int Hp = p.in_img / p.in_row, Wp = p.in_row;
+    const int yorg = p.y0 + ty * TH, xorg = p.x0 + tx * TW;            // patch origin in the padded input
+    float* coef_tab = (float*)(smem + COEF0);
+    if constexpr (EPI == EPI_BNB) bnb_fill_lds<BN, NT>(p, coef_tab, tid, 0);   // before the first LDS-DMA; read in the epilogue
+
+    // swizzle of a row (pixel or weight row) of the LDS images: chunk c of row r sits in slot c ^ swz(r)
+    auto swz = [](int r) { return CS == 64 ? (r >> 1) & 7 : (-(r >> 2)) & 3; };
+    auto stage_patch = [&](int slice) {
+        const bf16_t* src0 = (const bf16_t*)p.in + (int64_t)b * p.in_img * p.C + slice * CS;
+#pragma unroll
+        for (int i = 0; i < (PATCH_INSTR + 3) / 4; ++i) {
+            const int j = i * 4 + w;                                   // wave-uniform
+            if (j < PATCH_INSTR) {
+                int pix = j * PPI + lane / CPP;
+                pix = pix < NPIX ? pix : NPIX - 1;
+                const int py = (pix * 1928) >> 16, px = pix - py * PW;             // / 34, exact below 400
+                int iy = yorg + py, ix = xorg + px;
+                iy = iy < Hp ? iy : Hp - 1;                                        // tiles that overhang the image: rows / columns that are
+                ix = ix < Wp ? ix : Wp - 1;                                        // never stored read a valid pixel
+                const int chunk = (lane % CPP) ^ swz(j * PPI + lane / CPP);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + ((int64_t)iy * Wp + ix) * p.C + chunk * 8), LDS_PTR(patch + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int step, char* dst) {                          // step = slice * 9 + tap
+        const int slice = step / 9, tap = step - slice * 9;
+        int tw = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i == tap) tw = p.tap_w[i];
+        const bf16_t* src0 = (const bf16_t*)p.wt + (int64_t)tw * p.N * p.C + slice * CS;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int j = i * 4 + w;
+            const int n = j * PPI + lane / CPP;                        // < BN (whole instructions)
+            const int nn = n < p.N ? n : p.N - 1;
+            const int chunk = (lane % CPP) ^ swz(n);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + (int64_t)nn * p.C + chunk * 8), LDS_PTR(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][NTILE];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's A rows: wave w owns patch rows 2w, 2w + 1; tile mt = row (mt >> 1), x half (mt & 1); tap (dy, dx) adds dy * PW + dx
+    int pix0[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) pix0[mt] = (2 * w + (mt >> 1)) * PW + (mt & 1) * 16 + r16;
+    auto compute = [&](int tap, const char* wb) {
+        const int tapoff = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[4], bfr[NTILE];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int pix = pix0[mt] + tapoff;
+                af[mt] = *(const bf16x8*)(patch + pix * PIXB + (((ks * 4 + g) ^ swz(pix)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt) {
+                const int n = nt * 16 + r16;
+                bfr[nt] = *(const bf16x8*)(wb + n * PIXB + (((ks * 4 + g) ^ swz(n)) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTILE; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    if constexpr (RESIDENT) {
+        stage_patch(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) stage_w(t, wbuf + t * WSTEP_BYTES);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) compute(t, wbuf + t * WSTEP_BYTES);
+    } else {
+        // two weight slots: the matrix of step s + 1 is issued right after the barrier of step s, into the slot every wave has just
+        // finished reading; a new channel slice re-stages the patch at its first step (exposed once per tile: LDS holds one patch)
+        stage_patch(0);
+        stage_w(0, wbuf);
+#pragma unroll 1
+        for (int sl = 0; sl < NSL; ++sl) {                             // a runtime loop: unrolled, the 18 steps' addresses spill
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int s = sl * 9 + t;
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (NSL > 1 && t == 0 && sl > 0) {
+                    stage_patch(sl);
+                    stage_w(s + 1, wbuf + ((s + 1) & 1) * WSTEP_BYTES);
+                    wait_vmcnt<WPW>();                                 // the patch has landed, the next step's weights may still fly
+                    __builtin_amdgcn_s_barrier();
+                } else if (s + 1 < STEPS) {
+                    stage_w(s + 1, wbuf + ((s + 1) & 1) * WSTEP_BYTES);
+                }
+                compute(t, wbuf + (s & 1) * WSTEP_BYTES);
+            }
+        }
+    }
+    __syncthreads();   // LDS is free for the epilogue
+
+    // tile row of accumulator element (mt, j): patch pixel (2w + (mt >> 1), (mt & 1) * 16 + 4 g + j)
+    const bool full = (ty + 1) * TH <= p.pt_H && (tx + 1) * TW <= p.pt_W;
+    auto row_ok = [&](int rr) { return ty * TH + (rr >> 5) < p.pt_H && tx * TW + (rr & 31) < p.pt_W; };
+    if constexpr (EPI == EPI_STATS) {
+        if (p.stats != nullptr) {
+            float s1[NTILE], s2[NTILE];
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = full || row_ok((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + g * 4 + j);
+#pragma unroll
+                    for (int nt = 0; nt < NTILE; ++nt) {
+                        const float v = ok ? acc[mt][nt][j] : 0.f;
+                        s1[nt] += v;
+                        s2[nt] += v * v;
+                    }
+                }
+            float* red = (float*)smem;  // [2][4 waves][BN]
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) {
+                s1[i] += __shfl_xor(s1[i], 16);
+                s1[i] += __shfl_xor(s1[i], 32);
+                s2[i] += __shfl_xor(s2[i], 16);
+                s2[i] += __shfl_xor(s2[i], 32);
+                if (lane < 16) {
+                    red[(0 * 4 + w) * BN + i * 16 + lane] = s1[i];
+                    red[(1 * 4 + w) * BN + i * 16 + lane] = s2[i];
+                }
+            }
+            __syncthreads();
+            if (w < BN / 32) {
+                const int which = lane >> 5, col = w * 32 + (lane & 31);
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t += red[(which * 4 + k) * BN + col];
+                if (col < p.N) st_agent(p.stats + ((int64_t)tile * 2 + which) * p.N + col, t);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTILE; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(bf16_t*)(smem + ((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + g * 4 + j) * PITCH + (nt * 16 + r16) * 2) = (bf16_t)acc[mt][nt][j];
+    __syncthreads();
+    store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, 0, tile, [&](int rr) -> int64_t {
+        const int oy = ty * TH + (rr >> 5), ox = tx * TW + (rr & 31);
+        return oy < p.pt_H && ox < p.pt_W ? ((int64_t)b * p.pt_H + oy) * p.pt_W + ox : (int64_t)-1;
+    }, nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
+    if constexpr (EPI == EPI_STATS) {
+        if (p.tk.mode && p.stats != nullptr && w < BN / 32 && w * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), tile, w, lane);
+    }
+}
+
+// Layers the patch kernel serves (bf16, 3x3, stride 1): reduction channels C in {32, 64, 128}, outputs N in {32, 64, 128}, at most
+// C x N = 8192, on maps of at least 64 x 64 (below that the 8 x 32 patches overhang too much).  FVA_PCONV=0 switches it off.
+inline bool pconv_enabled() {
+    static bool v = [] { const char* e = getenv("FVA_PCONV"); return !e || atoi(e) != 0; }();
+    return v;
+}
+inline bool use_pconv(int dtype, int ksize, int stride, int C, int N, int H, int W) {
+    if (!pconv_enabled() || dtype != FVA_BF16 || ksize != 3 || stride != 1 || H < 64 || W < 64) return false;
+    return (C == 32 && N == 64) || (C == 64 && N == 128) || (C == 64 && N == 32) || (C == 128 && N == 64) || (C == 64 && N == 64);
+}
+inline int pconv_tiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 32); }
+
+template <int CS, int BN, int NSL, int EPI>
+int launch_pconv_one(const IgemmParams& p, int tiles, hipStream_t s) {
+    constexpr int PIXB = CS * 2, PPI = 1024 / PIXB, PATCH_BYTES = ((340 + PPI - 1) / PPI) * 1024, WSTEP = BN * PIXB;
+    constexpr bool RESIDENT = NSL == 1 && 9 * WSTEP <= 36 * 1024;
+    constexpr int WBUF = (RESIDENT ? 9 : 2) * WSTEP, TILE = 256 * (BN * 2 + 16);
+    constexpr int smem = (TILE > PATCH_BYTES + WBUF ? TILE : PATCH_BYTES + WBUF) + (EPI == EPI_BNB ? 4 * BN * 4 : 0);
+    static_assert(smem <= 80 * 1024, "two blocks per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)pconv_kernel<CS, BN, NSL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_kernel<CS, BN, NSL, EPI>), dim3(tiles), dim3(256), smem, s, p);
+    FVA_LAUNCH_CHECK("pconv_kernel");
+    return FVA_OK;
+}
+
+// p is set up as for igemm (in / wt / out / N / C / in_row / in_img / y0 / x0 / epilogue fields); H, W = output image; flip: data gradient
+template <int EPI>
+int launch_pconv(const IgemmParams& p0, int B, int H, int W, bool flip, hipStream_t s) {
+    IgemmParams p = p0;
+    p.pt_H = H;
+    p.pt_W = W;
+    p.pt_tx = cdiv(W, 32);
+    p.pt_ty = cdiv(H, 8);
+    p.pt_div_tx = make_fastdiv(p.pt_tx);
+    p.pt_div_img = make_fastdiv(p.pt_tx * p.pt_ty);
+    for (int t = 0; t < 9; ++t) p.tap_w[t] = flip ? 8 - t : t;     // patch tap (dy, dx) <-> filter tap: the data gradient flips both axes
+    const int tiles = pconv_tiles(B, H, W);
+    if (p.C == 32 && p.N == 64) return launch_pconv_one<32, 64, 1, EPI>(p, tiles, s);
+    if (p.C == 64 && p.N == 32) return launch_pconv_one<64, 32, 1, EPI>(p, tiles, s);
+    if (p.C == 64 && p.N == 64) return launch_pconv_one<64, 64, 1, EPI>(p, tiles, s);
+    if (p.C == 64 && p.N == 128) return launch_pconv_one<64, 128, 1, EPI>(p, tiles, s);
+    if (p.C == 128 && p.N == 64) return launch_pconv_one<64, 64, 2, EPI>(p, tiles, s);
+    return fva_fail(FVA_ERR_ARG, "pconv: unsupported channels %d -> %d", p.C, p.N);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -724,11 +999,19 @@ struct StreamK {
     int stamp_rows;      // blocks beyond the caller's buffer do not stamp
 };
 
-template <int EPI, bool SK>
+// MT = 16-row accumulator tiles per wave along m: 8 (a 256-row block) or 7 (224 rows).  At B = 32 the eligible layers have
+// 800 / 400 / 200 tiles of 256 x 256 for 256 CUs -- every launch ends with a round that fills 12-78 % of the chip -- while 224-row
+// tiles give 915 / 458 / 232: the same number of rounds of tiles that each cost 7/8 of the MFMA work (use_igemm8_mt picks).  The
+// LDS image keeps its 128-row half-tiles (the second half of a wave row holds 48 live rows; the other 16 are staged and never
+// read), so the staging, the swizzle and every hazard argument above are unchanged.
+template <int EPI, bool SK, int MT>
 __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const StreamK sk) {
-    constexpr int BM = 256, BN = 256, NT = 512, BK = 64;
+    static_assert(MT >= 5 && MT <= 8, "4 tiles in the first half of a wave row, 1-4 in the second");
+    constexpr int WM = 16 * MT;                       // rows of a wave row
+    constexpr int BM = 2 * WM, BN = 256, NT = 512, BK = 64;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;   // bytes
     constexpr int EPI_BYTES = BM * (BN * 2 + 16);     // the epilogue's transposed bf16 tile
+    constexpr int TAB0 = EPI_BYTES > 2 * BUF ? EPI_BYTES : 2 * BUF;   // tables that live across tiles: behind the staging buffers AND the epilogue tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
@@ -745,7 +1028,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int KT = p.ktiles;
 
-    int* ktab = (int*)(smem + EPI_BYTES);   // behind everything the epilogue touches: it lives across tiles
+    int* ktab = (int*)(smem + TAB0);
     for (int e = tid; e < KT; e += NT) {
         int t, kk;
         if (p.ktaps) { kk = e / p.ktaps; t = e - kk * p.ktaps; }
@@ -766,6 +1049,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 
     // this block's run of (tile, k-tile) units (the host keeps tiles * k-tiles * grid below 2^31)
     int u, u_end;
+    static_assert(!SK || MT == 8, "the stream-K slabs hold whole 256-row tiles");
     if constexpr (SK) {
         const int total = sk.tiles * KT;
         u = (int)((int64_t)total * logical / nwg);
@@ -783,7 +1067,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
         const int m0 = mblk * BM, n0 = nblk * BN;
         __syncthreads();   // ktab is written / the previous tile's epilogue is done with LDS
-        float* coef_tab = (float*)(smem + EPI_BYTES + 4096);
+        float* coef_tab = (float*)(smem + TAB0 + 4096);
         if constexpr (EPI == EPI_BNB) bnb_fill_lds<BN, NT>(p, coef_tab, tid, n0);   // read in the epilogue, many barriers later
 
         // ---- per-lane source rows of the LDS-DMA pieces: piece (i, w) of a half-tile = its rows (i*8 + w)*8 .. +8 ---
@@ -794,7 +1078,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int rh = (i * 8 + w) * 8 + lrow;                   // row inside the half-tile, 0..127
-                int m = m0 + (rh >> 6) * 128 + h * 64 + (rh & 63);
+                int m = m0 + (rh >> 6) * WM + h * 64 + (rh & 63);     // MT < 8: rows 16 (MT - 4) .. 63 of the second half are never read
                 m = m < p.M ? m : p.M - 1;
                 const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
                 const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
@@ -833,8 +1117,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             const char* q = buf + h * HALF + a_row;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
-                af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
+                if (h * 4 + mt < MT) {
+                    af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
+                    af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
+                }
             }
         };
         auto read_b = [&](const char* buf, int h, bf16x8 (&bf)[2][2]) {
@@ -853,8 +1139,9 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[ha * 4 + mt][hb * 2 + nt] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+                        if (ha * 4 + mt < MT)
+                            acc[ha * 4 + mt][hb * 2 + nt] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
         auto retire_reads_then_barrier = [&]() {
@@ -979,11 +1266,11 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         // visit the wave's 128x64 accumulator: (row, col) inside the block tile
         auto foreach = [&](auto&& f) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f(wr_e * 128 + mi * 16 + g_e * 4 + j, wc_e * 64 + ni * 16 + r_e, ni, acc[mi][ni][j]);
+                    for (int j = 0; j < 4; ++j) f(wr_e * WM + mi * 16 + g_e * 4 + j, wc_e * 64 + ni * 16 + r_e, ni, acc[mi][ni][j]);
         };
 
         if constexpr (EPI == EPI_STATS) {
@@ -1011,10 +1298,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                     }
                 }
                 __syncthreads();
-                {
-                    const int which = tid_e >> 8, col = tid_e & 255;
+                {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
+                    const int which = lane_e >> 5, col = (tid_e >> 6) * 32 + (lane_e & 31);
                     const float s = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
-                    if (n0 + col < p.N) p.stats[((int64_t)mblk * 2 + which) * p.N + n0 + col] = s;
+                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
                 }
                 __syncthreads();
             }
@@ -1035,7 +1322,11 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
         });
         __syncthreads();
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, m0, n0, mblk, out_pixel, nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
+                                                nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
+        if constexpr (EPI == EPI_STATS) {
+            if (p.tk.mode && p.stats != nullptr && n0 + (tid_e >> 6) * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), mblk, (n0 >> 5) + (tid_e >> 6), lane_e);
+        }
     }
     stamp(3);
 }
@@ -1093,6 +1384,22 @@ inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in
     return ktiles >= min_kt || tiles <= 256;
 }
 
+// Rows of the 8-phase kernel's block for a launch of M rows, N columns: 224 when that needs fewer MFMA-rounds than 256 -- rounds of
+// tiles on the chip's CUs x the tile's share of the work (ceil(tiles / CUs) x rows).  FVA_IGEMM8_BM=256 keeps the old tile (A/B aid).
+inline int igemm8_bm(int64_t M, int N, int64_t ktiles) {
+    static const int force = [] { const char* e = getenv("FVA_IGEMM8_BM"); return e ? atoi(e) : 0; }();
+    if (force == 224) return 224;
+    if (force != 1) return 256;            // measured equal or slower (profiles/r03_experiments.md): the chip is power-limited, not fill-limited
+    if (use_streamk((int64_t)cdiv(M, 256) * (N / 256), ktiles)) return 256;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const int64_t t8 = (int64_t)cdiv(M, 256) * (N / 256), t7 = (int64_t)cdiv(M, 224) * (N / 256);
+    return cdiv(t7, cus) * 7 < cdiv(t8, cus) * 8 ? 224 : 256;
+}
+
 long long* g_stamps = nullptr;   // fva_conv_debug_stamps
 int g_stamp_rows = 0;
 
@@ -1100,24 +1407,28 @@ template <int EPI>
 int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     IgemmParams q = p;
     q.nblocks = p.N / 256;
-    const int tiles = cdiv(p.M, 256) * q.nblocks;
+    const int bm = igemm8_bm(p.M, p.N, p.ktiles);
+    const int tiles = cdiv(p.M, bm) * q.nblocks;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
         attr_done = true;
     }
     StreamK sk{};
     sk.stamps = g_stamps;
     sk.stamp_rows = g_stamp_rows;
-    if (use_streamk(tiles, p.ktiles)) {
+    if (bm == 256 && use_streamk(tiles, p.ktiles)) {
         sk.slabs = g_sk.slabs;
         sk.flags = g_sk.flags;
         sk.epoch = ++g_sk.epoch;
         sk.tiles = tiles;
-        hipLaunchKernelGGL((igemm8_kernel<EPI, true>), dim3(g_sk.grid), dim3(512), IGEMM8_SMEM, s, q, sk);
+        hipLaunchKernelGGL((igemm8_kernel<EPI, true, 8>), dim3(g_sk.grid), dim3(512), IGEMM8_SMEM, s, q, sk);
+    } else if (bm == 224) {
+        hipLaunchKernelGGL((igemm8_kernel<EPI, false, 7>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
     } else {
-        hipLaunchKernelGGL((igemm8_kernel<EPI, false>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
+        hipLaunchKernelGGL((igemm8_kernel<EPI, false, 8>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
     }
     FVA_LAUNCH_CHECK("igemm8_kernel");
     return FVA_OK;
@@ -1377,11 +1688,12 @@ int fva_conv_pack_weights_multi(const fva_pack_entry* table_dev, int32_t n, int6
 
 int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
     if (!d) return 0;
+    if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return pconv_tiles(d->B, d->H, d->W);
     const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
     const int64_t M = (int64_t)d->B * OH * OW;
     const int64_t in_img = (int64_t)(d->H + 2 * d->in_pad) * (d->W + 2 * d->in_pad);
     if (!halfrow_mode(d->dtype, d->Cin) && use_igemm8(d->dtype, M, d->Cout, d->Cin, d->ksize * d->ksize, (M / ((int64_t)OH * OW) + 1) * in_img))
-        return cdiv(M, 256);
+        return cdiv(M, igemm8_bm(M, d->Cout, (int64_t)d->ksize * d->ksize * (d->Cin / 64)));
     return cdiv(M, tile_bm(d->dtype, (int)M, d->Cout));
 }
 
@@ -1412,13 +1724,44 @@ static int setup_fwd(const fva_conv_desc* d, IgemmParams& p, const char* who) {
             ++nt;
         }
     p.tap_w[nt] = k * k;  // zero tap (present in packed weights when needed)
+    {   // EXPERIMENT (results wrong): every tap reads the centre tap's pixels -> what the L2 -> LDS re-reads of the nine taps cost
+        static const bool centre = [] { const char* e = getenv("FVA_TAP_CENTRE"); return e && atoi(e) != 0; }();
+        if (centre) for (int i = 0; i < nt; ++i) p.tap_pix[i] = p.tap_pix[nt / 2];
+    }
     finish_taps(p, nt, d->dtype);
     p.out_dense = 1;
     p.out_pitch = d->Cout;
     return FVA_OK;
 }
 
+int32_t fva_bn_ticket_groups(int32_t rows) { return rows > 0 ? cdiv(rows, bn_ticket_group_rows(rows)) : 0; }
+int64_t fva_bn_ticket_counters(int32_t rows, int32_t C) { return rows > 0 && C > 0 ? (int64_t)(fva_bn_ticket_groups(rows) + 1) * cdiv(C, 32) : 0; }
+
+// common part of the two ticket descriptors: geometry of the table and the scratch the fold needs
+static int ticket_base(BnTicket& t, int mode, int rows, int C, int64_t count, int32_t* counters, double* group_sums, const float* part,
+                       const char* who) {
+    if (C % 32) return fva_fail(FVA_ERR_ARG, "%s: in-launch BatchNorm finalisation needs C %% 32 == 0 (C = %d)", who, C);
+    if (!counters || !part || rows < 1) return fva_fail(FVA_ERR_ARG, "%s: in-launch BatchNorm finalisation: null counters / table", who);
+    t = BnTicket();
+    t.mode = mode;
+    t.rows = rows;
+    t.G = bn_ticket_group_rows(rows);
+    t.ngroups = cdiv(rows, t.G);
+    if (t.ngroups > 1 && !group_sums) return fva_fail(FVA_ERR_ARG, "%s: %d row groups need group_sums", who, t.ngroups);
+    t.C = C;
+    t.counters = counters;
+    t.gsum = group_sums;
+    t.part = part;
+    t.count = (double)count;
+    return FVA_OK;
+}
+
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream) {
+    return fva_conv_fwd_bn(d, x, w_fwd, y, stats_partial, nullptr, stream);
+}
+
+int fva_conv_fwd_bn(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, const fva_bn_fwd_fin* fin,
+                    void* stream) {
     IgemmParams p;
     int rc = setup_fwd(d, p, "fva_conv_fwd");
     if (rc) return rc;
@@ -1428,7 +1771,19 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
     p.wt = w_fwd;
     p.out = y;
     p.stats = stats_partial;
+    if (fin) {
+        if (!stats_partial || !fin->gamma || !fin->beta || !fin->save_mean || !fin->save_rstd || !fin->scale || !fin->shift)
+            return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bn: null pointer");
+        rc = ticket_base(p.tk, 1, fva_conv_stat_blocks(d), d->Cout, p.M, fin->counters, fin->group_sums, stats_partial, "fva_conv_fwd_bn");
+        if (rc) return rc;
+        p.tk.gamma = fin->gamma; p.tk.beta = fin->beta;
+        p.tk.running_mean = fin->running_mean; p.tk.running_var = fin->running_var;
+        p.tk.nbt = (long long*)fin->num_batches_tracked;
+        p.tk.momentum = fin->momentum; p.tk.eps = fin->eps;
+        p.tk.save_mean = fin->save_mean; p.tk.save_rstd = fin->save_rstd; p.tk.scale = fin->scale; p.tk.shift = fin->shift;
+    }
     FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return launch_pconv<EPI_STATS>(p, d->B, d->H, d->W, false, (hipStream_t)stream);
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
 }
 
@@ -1499,7 +1854,7 @@ int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const
 
 // row blocks (BM of the tile the dispatcher picks) of ONE dgrad launch with m rows, n columns, reduction over c channels x ntaps
 static int dgrad_launch_rows(const fva_conv_desc* d, int64_t m, int n, int c, int ntaps, int64_t in_pixels) {
-    if (!halfrow_mode(d->dtype, c) && use_igemm8(d->dtype, m, n, c, ntaps, in_pixels)) return cdiv(m, 256);
+    if (!halfrow_mode(d->dtype, c) && use_igemm8(d->dtype, m, n, c, ntaps, in_pixels)) return cdiv(m, igemm8_bm(m, n, (int64_t)ntaps * (c / 64)));
     return cdiv(m, tile_bm(d->dtype, (int)m, n));
 }
 
@@ -1508,6 +1863,7 @@ int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d) {
     const int k = d->ksize, s = d->stride;
     const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
     const int64_t in_pixels = (int64_t)(d->B + 1) * (OH + 2 * d->dy_pad) * (OW + 2 * d->dy_pad);
+    if (use_pconv(d->dtype, k, s, d->Cout, d->Cin, d->H, d->W)) return pconv_tiles(d->B, d->H, d->W);
     if (s == 1) return dgrad_launch_rows(d, (int64_t)d->B * d->H * d->W, d->Cin, d->Cout, k * k, in_pixels);
     const int64_t mq = (int64_t)d->B * (d->H / 2) * (d->W / 2);
     if (dgrad_paired(k, s, d->Cin)) {   // two launches (row parity) of N' = 2 * Cin columns: two table rows per block
@@ -1522,11 +1878,16 @@ int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d) {
 }
 
 int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream) {
-    return fva_conv_dgrad_bnstats(d, dy, w_dgrad, dx, addend, nullptr, stream);
+    return fva_conv_dgrad_bn(d, dy, w_dgrad, dx, addend, nullptr, nullptr, stream);
 }
 
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* f, void* stream) {
+    return fva_conv_dgrad_bn(d, dy, w_dgrad, dx, addend, f, nullptr, stream);
+}
+
+int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
+                      const fva_bn_bwd_fuse* f, const fva_bn_bwd_fin* fin, void* stream) {
     int rc = check_desc(d, "fva_conv_dgrad");
     if (rc) return rc;
     rc = check_red_channels(d->dtype, d->Cout, "fva_conv_dgrad");
@@ -1554,6 +1915,17 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
         p.bnb_part = f->partial;
         p.bnb_row0 = 0;
         p.bnb_C = d->Cin;
+        if (fin) {
+            if (!fin->gamma || !fin->dgamma || !fin->dbeta || !fin->coef) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bn: null pointer");
+            rc = ticket_base(p.tk, 2, fva_conv_dgrad_stat_rows(d), d->Cin, (int64_t)d->B * d->H * d->W, fin->counters, fin->group_sums,
+                             f->partial, "fva_conv_dgrad_bn");
+            if (rc) return rc;
+            p.tk.gamma = fin->gamma; p.tk.rstd = f->rstd;
+            p.tk.dgamma = fin->dgamma; p.tk.dbeta = fin->dbeta; p.tk.coef = fin->coef;
+            p.tk.accumulate = fin->accumulate;
+        }
+    } else if (fin) {
+        return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bn: a finalisation descriptor needs the fused statistics (fuse != NULL)");
     }
     const int64_t in_pixels = (int64_t)(d->B + 1) * (OH + 2 * d->dy_pad) * (OW + 2 * d->dy_pad);
     if (s == 1) {
@@ -1573,6 +1945,8 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
         p.tap_w[nt] = k * k;
         finish_taps(p, nt, d->dtype);
         p.out_dense = 1;
+        if (use_pconv(d->dtype, k, s, d->Cout, d->Cin, d->H, d->W))
+            return f ? launch_pconv<EPI_BNB>(p, d->B, d->H, d->W, true, (hipStream_t)stream) : launch_pconv<EPI_PLAIN>(p, d->B, d->H, d->W, true, (hipStream_t)stream);
         return f ? launch_igemm<EPI_BNB>(d->dtype, p, (hipStream_t)stream) : launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
     }
     const int JH = d->H / 2, JW = d->W / 2;

@@ -555,43 +555,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// The same reduction with 16-byte loads: a block owns 256 consecutive (n,c) pairs (64 lanes x float4) x 4 split-K groups.  The
-// 4-byte version above moves 256 B per wave instruction and ran at 1.45 TB/s over the 3.2 GB of slabs a step writes (2.2 ms for the
-// 75 launches); this one is used whenever N*C is a multiple of 4 (every layer but odd test shapes).
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N, int C,
-                                                            int ntaps, int ksplit, int accumulate) {
-    extern __shared__ float rsm[];                       // part[4][ntaps][256] then outs[256 * ntaps]
+// The same reduction with 16-byte loads, built for bandwidth: a block owns 256 consecutive (n,c) pairs (64 lanes x float4) x all
+// taps x KG split-K groups (KG waves: 4, 8 or 16, chosen so that every thread sums a handful of slabs).  Round 2's version gave a
+// thread ksplit / 4 slabs of ONE tap at a time with four loads in flight -- 16-32 dependent round trips for a 1x1 layer with 256
+// splits: 25 us per launch on average, 1.9 ms per step, latency not bytes.  Here a thread issues the loads of ALL taps of up to
+// four slabs together (up to 36 in flight), so a launch is one to four round trips.  The sum order is fixed: slabs of a group in
+// index order, groups in index order (deterministic; the grouping differs from round 2's, so results differ in the last bits).
+template <int TAPS>
+__global__ __launch_bounds__(1024) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N, int C,
+                                                             int ksplit, int accumulate, int kg) {
+    extern __shared__ float rsm[];                       // part[kg][TAPS][256] then outs[256 * TAPS]
     float* part = rsm;
-    float* outs = rsm + 4 * ntaps * 256;
+    float* outs = rsm + kg * TAPS * 256;
     const int64_t nc = (int64_t)N * C;
     const int64_t i0 = (int64_t)blockIdx.x * 256;
     const int li = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = i0 + li * 4;
-    const int64_t kstride = (int64_t)ntaps * nc;
-    for (int t = 0; t < ntaps; ++t) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (i < nc) {
-            const float* src = slab + (int64_t)t * nc + i;
-            int k = grp;
-            for (; k + 12 < ksplit; k += 16) {
-                const f32x4 v0 = *(const f32x4*)(src + (int64_t)k * kstride), v1 = *(const f32x4*)(src + (int64_t)(k + 4) * kstride);
-                const f32x4 v2 = *(const f32x4*)(src + (int64_t)(k + 8) * kstride), v3 = *(const f32x4*)(src + (int64_t)(k + 12) * kstride);
-                s += (v0 + v1) + (v2 + v3);
-            }
-            for (; k < ksplit; k += 4) s += *(const f32x4*)(src + (int64_t)k * kstride);
+    const int64_t kstride = (int64_t)TAPS * nc;
+    f32x4 s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < nc) {
+        const float* src = slab + i;
+        constexpr int KU = TAPS == 1 ? 8 : 4;            // slabs in flight per thread
+        int k = grp;
+        for (; k + (KU - 1) * kg < ksplit; k += KU * kg) {
+            f32x4 v[KU][TAPS];
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) v[u][t] = *(const f32x4*)(src + (int64_t)(k + u * kg) * kstride + (int64_t)t * nc);
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) s[t] += v[u][t];
         }
-        *(f32x4*)(part + ((grp * ntaps + t) * 256 + li * 4)) = s;
+        for (; k < ksplit; k += kg) {
+            f32x4 v[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[t] = *(const f32x4*)(src + (int64_t)k * kstride + (int64_t)t * nc);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s[t] += v[t];
+        }
     }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) *(f32x4*)(part + ((grp * TAPS + t) * 256 + li * 4)) = s[t];
     __syncthreads();
-    for (int e = threadIdx.x; e < 256 * ntaps; e += 256) {
+    for (int e = threadIdx.x; e < 256 * TAPS; e += blockDim.x) {
         const int t = e / 256, l = e - t * 256;
-        outs[l * ntaps + t] = (part[(0 * ntaps + t) * 256 + l] + part[(1 * ntaps + t) * 256 + l]) +
-                              (part[(2 * ntaps + t) * 256 + l] + part[(3 * ntaps + t) * 256 + l]);
+        float a = 0.f;
+        for (int g = 0; g < kg; ++g) a += part[(g * TAPS + t) * 256 + l];
+        outs[l * TAPS + t] = a;
     }
     __syncthreads();
-    const int64_t valid = (nc - i0 < 256 ? nc - i0 : 256) * ntaps;
-    for (int e = threadIdx.x; e < valid; e += 256) {
-        float* o = dw + i0 * ntaps + e;
+    const int64_t valid = (nc - i0 < 256 ? nc - i0 : 256) * TAPS;
+    for (int e = threadIdx.x; e < valid; e += blockDim.x) {
+        float* o = dw + i0 * TAPS + e;
         *o = accumulate ? *o + outs[e] : outs[e];
     }
 }
@@ -641,7 +660,11 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     if (kmax > max_by_ws) kmax = (int)max_by_ws;
     if (kmax < 1) kmax = 1;
     // the 256x256 8-phase kernel runs one block per CU (256 slots) at ~4.3 TFLOP/s per block
-    const int slots = pl.tile == 256 ? 256 : 512;
+    // FVA_WGRAD_SLOTS8 / FVA_WGRAD_SLOTS (experiment): plan for fewer resident blocks than the chip holds -- fewer, longer blocks and
+    // less slab traffic, leaving CUs to the launch stream when the weight gradients run beside it
+    static const int slots8 = [] { const char* e = getenv("FVA_WGRAD_SLOTS8"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+    static const int slots4 = [] { const char* e = getenv("FVA_WGRAD_SLOTS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    const int slots = pl.tile == 256 ? slots8 : slots4;
     const double t_full = 2.0 * pl.M * pl.tile * pl.tile / (pl.tile == 256 ? 4.3e12 : 1.6e12);
     const double t_slab = (double)per * 2.0 / 3.0e12 + 0.05e-6;
     int ks = 1;
@@ -734,10 +757,25 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
     FVA_LAUNCH_CHECK("wgrad_kernel");
     const int64_t nc = (int64_t)d->Cout * d->Cin;
     static const bool reduce4 = [] { const char* e = getenv("FVA_WGRAD_REDUCE4"); return !e || atoi(e) != 0; }();   // =0: A/B aid
-    if (reduce4 && nc % 4 == 0 && ((uintptr_t)workspace & 15) == 0)
-        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((int)((nc + 255) / 256)), dim3(256), pl.ntaps * 5 * 256 * 4, s, (const float*)workspace, dw,
-                           d->Cout, d->Cin, pl.ntaps, pl.ksplit, accumulate);
-    else
+    if (reduce4 && nc % 4 == 0 && ((uintptr_t)workspace & 15) == 0 && (pl.ntaps == 1 || pl.ntaps == 9)) {
+        // split-K groups per block: enough that a thread sums at most ~8 (1x1) / ~4 (3x3) slabs, and that small layers still put
+        // a few hundred waves on the chip
+        int kg = 4;                                     // 3x3: four groups (nine taps x four slabs = 36 loads in flight per thread; 46 KiB of LDS)
+        if (pl.ntaps == 1)
+            while (kg < 16 && kg * 8 < pl.ksplit) kg *= 2;
+        const int smem_r = (kg + 1) * pl.ntaps * 256 * 4;
+        const dim3 grid((int)((nc + 255) / 256)), block(64 * kg);
+        if (pl.ntaps == 1) {
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, grid, block, smem_r, s, (const float*)workspace, dw, d->Cout, d->Cin, pl.ksplit, accumulate, kg);
+        } else {
+            static bool attr9 = false;
+            if (!attr9) {
+                (void)hipFuncSetAttribute((const void*)wgrad_reduce4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 9 * 256 * 4);
+                attr9 = true;
+            }
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<9>, grid, block, smem_r, s, (const float*)workspace, dw, d->Cout, d->Cin, pl.ksplit, accumulate, kg);
+        }
+    } else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((nc + 63) / 64)), dim3(256), 0, s, (const float*)workspace, dw, d->Cout,
                            d->Cin, pl.ntaps, pl.ksplit, accumulate);
     FVA_LAUNCH_CHECK("wgrad_reduce_kernel");

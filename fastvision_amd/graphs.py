@@ -50,16 +50,22 @@ class GraphedTrainStep:
       * the target table: a fixed-capacity [max_targets, 6] buffer whose unused rows are zero.  A zero-size box matches no anchor
         (loss/yolov3_loss.py:98-99: max(r, 1/r) = inf), so the library loss sees exactly the rows the reference would; the demo
         loss assigns EVERY row to its best anchor, so it must be captured with its exact target count (max_targets=None).
-    The captured sequence includes the weight re-pack, the weight gradients on the library's side stream, BatchNorm running
-    statistics and the optimizer.  Results are bit-identical with the eager step (same kernels, same order, same addresses'
-    contents); ``tests/test_gpu_graph.py`` checks that.
+    The captured sequence includes the weight re-pack, the weight gradients, BatchNorm running statistics and the optimizer.
+    Results are bit-identical with the eager step (same kernels, same order, same addresses' contents);
+    ``tests/test_gpu_graph.py`` checks that.
+    ``side_stream`` (default False): capture on ONE stream.  A second graph branch for the weight gradients replays at equal
+    priority and takes CUs from the critical path -- 43-44 ms instead of 32 per YOLOv3 step (the eager
+    step's side stream is low-priority, which graph kernel nodes cannot be on this runtime) -- so the library's side stream is
+    switched off around warm-up and capture and put back afterwards; pass True to capture the two-branch form anyway.
+    Several graphs may be captured on one optimizer (another batch size, a re-capture): each owns its pointer-table staging.
 
         step = GraphedTrainStep(model, lambda pred, tg: criterion(pred, tg), optimizer, images, targets, max_targets=1280)
         for images, targets in loader:
             loss = step(images, targets)          # a device tensor, overwritten by the next call
     """
 
-    def __init__(self, model, loss_fn, optimizer, images, targets, max_targets=None, warmup=2, pre_step=None, on_capture=None):
+    def __init__(self, model, loss_fn, optimizer, images, targets, max_targets=None, warmup=2, pre_step=None, on_capture=None,
+                 side_stream=False):
         if not getattr(optimizer, 'capturable', False):
             raise RuntimeError('GraphedTrainStep needs FusedAdam(..., capturable=True): step count and LR must live on the device')
         if not model.training:
@@ -75,23 +81,29 @@ class GraphedTrainStep:
         self.targets[:T].copy_(targets)
         # warm-up steps do the lazy one-time work (kernel attributes, pointer tables, allocator growth, Adam state) -- on a copy of
         # the training state that is put back afterwards, so that capture leaves parameters, statistics and moments untouched
-        snap = self._snapshot()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._restore(snap)
-        optimizer.zero_grad(set_to_none=True)
-        torch.autograd.graph.increment_version(self.params)          # the captured sequence must start with the weight re-pack
-        steps_before = [optimizer._step_of(p) if optimizer.state.get(p) else None for p in self.params]
-        if on_capture is not None:
-            on_capture()                                             # e.g. arm the library's event spans: they become graph nodes
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._step()
+        from . import ops
+        side_was = ops.set_wgrad_side_stream(bool(side_stream) and ops._SIDE['on'])
+        try:
+            snap = self._snapshot()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._restore(snap)
+            optimizer.zero_grad(set_to_none=True)
+            torch.autograd.graph.increment_version(self.params)      # the captured sequence must start with the weight re-pack
+            steps_before = [optimizer._step_of(p) if optimizer.state.get(p) else None for p in self.params]
+            self._adam_staging = optimizer.begin_capture()           # this graph's own pointer-table words (kept alive with it)
+            if on_capture is not None:
+                on_capture()                                         # e.g. arm the library's event spans: they become graph nodes
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step()
+        finally:
+            ops.set_wgrad_side_stream(side_was)
         for p, st in zip(self.params, steps_before):                 # capture ran the host side of optimizer.step() once
             if st is not None:
                 optimizer.state[p]['step'] = st

@@ -256,6 +256,37 @@ def set_bn_backward_fusion(on):
     return prev
 
 
+# ---- BatchNorm finalisation inside the producing launch (csrc/bn_ticket.h) -----------------------------------------------------
+# The waves that write a partial-statistics table draw tickets; the last arriver folds and finalises: no bn_finalize /
+# bn_bwd_finalize / bn_prereduce launch (197 per YOLOv3 step).  Built in round 3 and MEASURED SLOWER than the launches it removes
+# (profiles/r03_ticket_tail.md: the fold is a chain of dependent memory round trips -- drain, ticket, rows, drain, ticket, groups --
+# at the very end of the producing launch, 6-36 us per layer against 4-11 us for the stand-alone finalize launch, whose cost in a
+# back-to-back chain turned out to be 0.95 ms per step, not the 2.0 ms of summed kernel durations), so it is OFF by default
+# (env FVA_BN_TICKET=1 / set_bn_ticket_finalize(True) turn it on; tests/test_gpu_bn_ticket.py keeps it correct).  The ticket
+# counters live on the BatchNorm weight (zero-filled once; every launch leaves them zero), one set per direction.
+_BN_TICKET = [os.environ.get('FVA_BN_TICKET', '0') != '0']
+
+
+def set_bn_ticket_finalize(on):
+    """Switch the in-launch BatchNorm finalisation on or off (default off; env FVA_BN_TICKET=1).  Returns the previous setting."""
+    prev = _BN_TICKET[0]
+    _BN_TICKET[0] = bool(on)
+    return prev
+
+
+def _ticket_scratch(gamma, tag, rows, Cc):
+    """(counters, group_sums) for a table of ``rows`` rows of ``Cc`` channels; the counters persist on ``gamma``."""
+    lib = _lib.load()
+    key = (rows, Cc, gamma.device)
+    hit = getattr(gamma, tag, None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.zeros(lib.fva_bn_ticket_counters(rows, Cc), dtype=torch.int32, device=gamma.device))
+        setattr(gamma, tag, hit)
+    ng = lib.fva_bn_ticket_groups(rows)
+    gs = torch.empty((ng, 2, Cc), dtype=torch.float64, device=gamma.device) if ng > 1 else None
+    return hit[1], gs
+
+
 def _note_consumer(x):
     """A consumer of x that will hand back a gradient: called by every autograd node of this module in forward."""
     src = getattr(x, '_fva_prod', None)
@@ -274,11 +305,24 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
     if (_BN_FUSE[0] and src is not None and src.consumers == 1 and src.training and src.dtype == dtype
             and src.M == d.B * d.H * d.W and src.d.Cout == d.Cin and not torch.is_grad_enabled()):
         rows = _lib.load().fva_conv_dgrad_stat_rows(C.byref(d))
+        if rows > 0 and _BN_TICKET[0] and d.Cin % 32 == 0:
+            # ... and the finalisation too: dgamma / dbeta / the pass-2 coefficients of the producer leave this launch
+            part = torch.empty((rows, 2, d.Cin), dtype=torch.float32, device=dx.device)
+            fs = _fuse_struct(src, part)
+            cnt, gs = _ticket_scratch(src.gamma, '_fva_tk_bwd', rows, d.Cin)
+            dgamma = torch.empty(d.Cin, dtype=torch.float32, device=dx.device)
+            dbeta = torch.empty_like(dgamma)
+            coef = torch.empty((3, d.Cin), dtype=torch.float32, device=dx.device)
+            fin = _lib.BnBwdFin(cnt.data_ptr(), gs.data_ptr() if gs is not None else None, src.gamma.data_ptr(), dgamma.data_ptr(),
+                                dbeta.data_ptr(), coef.data_ptr(), 0)
+            _lib.call('fva_conv_dgrad_bn', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), C.byref(fin), _stream())
+            src.fused = (part, rows, dx.data_ptr(), dx, (dgamma, dbeta, coef), gs)
+            return
         if rows > 0:
             part = torch.empty((_lib.load().fva_bn_partial_rows(rows), 2, d.Cin), dtype=torch.float32, device=dx.device)
             fs = _fuse_struct(src, part)
             _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
-            src.fused = (part, rows, dx.data_ptr(), dx)
+            src.fused = (part, rows, dx.data_ptr(), dx, None, None)
             return
     _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
 
@@ -319,18 +363,28 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     y = torch.empty((M, Cout), dtype=dtype, device=dev)
     if training:
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
-        stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
-        _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
-        _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
-                  bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+        if _BN_TICKET[0] and Cout % 32 == 0:
+            stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
+            cnt, gs = _ticket_scratch(gamma, '_fva_tk_fwd', nblk, Cout)
+            fin = _lib.BnFwdFin(cnt.data_ptr(), gs.data_ptr() if gs is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                                bn.rm.data_ptr(), bn.rv.data_ptr(), bn.nbt.data_ptr(), bn.momentum, bn.eps, mean.data_ptr(),
+                                rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            _lib.call('fva_conv_fwd_bn', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), C.byref(fin), _stream())
+            del gs          # stream-ordered allocator: the apply pass that follows is enqueued behind the launch that uses it
+        else:
+            stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
+            _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+            _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                      bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
     else:
         _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), C.c_void_p(0), _stream())
         _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
     zbuf, z = halo_alloc(B, Cout, OH, OW, dtype, dev, 1)
     rp, rpad = (C.c_void_p(residual[0]), residual[1]) if residual is not None else (C.c_void_p(0), 0)
-    _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
+    if not _ABLATE['apply']:
+        _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
     s = None
     if need_ctx:
         s = _Saved()
@@ -449,6 +503,10 @@ def wgrad_stream(buffers, weight=None):
     return side
 
 
+# timing experiments only (results wrong): FVA_ABLATE=wgrad,apply,... skips those launches to see what they cost the step
+_ABLATE = {k: k in os.environ.get('FVA_ABLATE', '').split(',') for k in ('wgrad', 'apply', 'bwd_apply', 'dgrad')}
+
+
 def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     """Backward of conv_block_fwd given dz (dense NHWC, dtype).  Returns (dx_buf or None, dw, dgamma, dbeta)."""
     if not s.training:
@@ -457,29 +515,36 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     d, dtype, dev = s.d, s.dtype, s.y.device
     Cout, code = d.Cout, _code(s.dtype)
     fused, s.fused = s.fused, None
+    done = None
     if fused is not None and fused[2] == dz_ptr:
-        part, nb = fused[0], fused[1]              # the consumer's dgrad epilogue has already summed dU and dU * xhat
+        part, nb, done = fused[0], fused[1], fused[4]   # the consumer's dgrad epilogue has already summed dU and dU * xhat
     else:
         nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
         part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
                   _p(part), nb, s.M, Cout, _stream())
     del fused
-    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-    dbeta = torch.empty_like(dgamma)
-    coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-    _lib.call('fva_bn_bwd_finalize', _p(part), nb, s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+    if done is not None:
+        dgamma, dbeta, coef = done                      # ... and finalised them in the same launch (bn_ticket.h)
+    else:
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
     dy = torch.empty((d.B, s.OH + 2, s.OW + 2, Cout), dtype=dtype, device=dev)
-    _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-              _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+    if not _ABLATE['bwd_apply']:
+        _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                  _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, wgrad_stream((s.x, getattr(s, 'keep', None), dy, ws), s.weight))     # NOT dw: a second reference makes AccumulateGrad clone it (on the main stream)
+    if not _ABLATE['wgrad']:
+        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, wgrad_stream((s.x, getattr(s, 'keep', None), dy, ws), s.weight))     # NOT dw: a second reference makes AccumulateGrad clone it (on the main stream)
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
-        _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
+        if not _ABLATE['dgrad']:
+            _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
     return dx, dw, dgamma, dbeta
 
 
@@ -540,7 +605,7 @@ class StemFn(torch.autograd.Function):
                 stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
                 _lib.call('fva_stem_fused', 0, _p(ws), _p(weight), None, None, None, None, None, None, None, _p(stats), B, Cin, H, W, _stream())
                 mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
-                _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
                           bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
             else:
                 _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
@@ -556,7 +621,7 @@ class StemFn(torch.autograd.Function):
             stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
             _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), _p(stats), _p(ws), wsb, B, Cin, H, W, Cout, _stream())
             mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
-            _lib.call('fva_bn_finalize', _p(stats), nblk, M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+            _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
                       bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
         else:
             _lib.call('fva_stem_fwd', code, _p(img), _p(weight), _p(y), C.c_void_p(0), _p(ws), wsb, B, Cin, H, W, Cout, _stream())
@@ -589,7 +654,7 @@ class StemFn(torch.autograd.Function):
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
             dbeta = torch.empty_like(dgamma)
             coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-            _lib.call('fva_bn_bwd_finalize', _p(part), nb, M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+            _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
             dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
             _lib.call('fva_stem_fused', 3, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
                       _p(dy), None, B, Cin, H, W, _stream())
@@ -605,7 +670,7 @@ class StemFn(torch.autograd.Function):
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty_like(dgamma)
         coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-        _lib.call('fva_bn_bwd_finalize', _p(part), nb, M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+        _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
         if ctx.img4 is not None and os.environ.get('FVA_STEM_WGRAD_MFMA', '1') != '0':
             # MFMA path: dY as a halo buffer, conv0 seen as 3 vertical taps over 4-pixel windows of the NHWC4 image
             dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)

@@ -66,7 +66,7 @@ class FusedAdam(torch.optim.Optimizer):
                 # (warm-up) step; the captured copy node re-reads the same pinned words on every replay
                 d = self._dev.get(gi)
                 if d is None or d.get('pinned') is None or d['pinned'].numel() != len(vals):
-                    raise RuntimeError('FusedAdam: run at least one eager step() (capturable=True) before capturing a graph')
+                    raise RuntimeError('FusedAdam: run at least one eager step() (capturable=True) and begin_capture() before capturing a graph')
                 host, both = d['pinned'], d['table']
                 host.copy_(torch.tensor(vals, dtype=torch.int64))
                 both.copy_(host, non_blocking=True)
@@ -86,6 +86,21 @@ class FusedAdam(torch.optim.Optimizer):
             hit = (key, tab, sizes, n, max(p.numel() for p in ps), host)
             self._tables[gi] = hit
         return ps, hit
+
+    def begin_capture(self):
+        """Fresh staging buffers for ONE graph capture (call right before ``torch.cuda.graph``, after a warm-up step).  The captured
+        copy node re-reads the pinned words it was recorded with on every replay, so every graph needs words of its own: with one
+        shared buffer a second capture on the same optimizer (another batch size, a re-capture) rewrote the pointers the first
+        graph's Adam launch reads.  Returns the buffers: the graph's owner keeps them alive as long as the graph."""
+        owned = []
+        for gi, d in self._dev.items():
+            if d.get('pinned') is not None:
+                n = d['pinned'].numel()
+                d['pinned'] = torch.empty(n, dtype=torch.int64).pin_memory()
+                d['table'] = torch.empty(n, dtype=torch.int64, device=d['state'].device)
+                owned.append((d['pinned'], d['table']))
+        self._tables.clear()              # the capture-time step must write (and record the upload of) its own table
+        return owned
 
     def _dev_state(self, gi, group, dev):
         d = self._dev.get(gi)

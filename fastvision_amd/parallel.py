@@ -1,16 +1,27 @@
-"""Data parallelism for the hot path: one process per GPU, gradients all-reduced over RCCL/xGMI in buckets that
-are launched while the backward pass is still running.
+"""Data parallelism for the hot path: one process per GPU, gradients all-reduced over RCCL/xGMI in buckets that are launched
+while the backward pass is still running.
 
-The reference only has single-process ``nn.DataParallel`` (demos/yolov3_u/train.py:85), which re-broadcasts the
-248 MB of parameters and gathers outputs to GPU 0 every step.  This replacement keeps its *semantics* where they
-matter -- per-GPU BatchNorm statistics (no SyncBN), replicated parameters -- and changes the mechanics: each rank
-computes the loss on its own 32 images and the 61.9 M gradients are averaged by one bucketed all-reduce
-(DDP semantics; the difference from DataParallel's loss-over-the-gathered-batch is documented in DESIGN.md).
+The reference only has single-process ``nn.DataParallel`` (demos/yolov3_u/train.py:85), which re-broadcasts the 248 MB of
+parameters and gathers the outputs to GPU 0 every step, where ONE loss is evaluated on the gathered batch
+(demos/yolov3_u/cfg/_fit.py:48-51).  This replacement keeps those semantics -- replicated parameters, per-GPU BatchNorm statistics
+(no SyncBN), and the gradient of the loss over the WHOLE batch -- and changes the mechanics: each rank evaluates the loss on its own
+32 images; the library's ``Yolov3Loss`` (means x batch size, loss/yolov3_loss.py:69-71) normalises its per-match sums by the match
+counts of the whole job (``Yolov3Loss.data_parallel()``, a 12-byte all-reduce) and the ranks' gradients are SUMMED
+(``GradientReducer(average=False)``); the demo's ``ComputeLoss`` is a plain mean, so its gradients are AVERAGED
+(``average=True``).  Checked against the CPU oracle evaluated on the gathered batch
+(tests/test_gpu_model.py::test_data_parallel_reproduces_the_reference_dataparallel_step).
 
-xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound by one link: buckets are kept large
-(default 32 MiB, ~8 buckets) to amortise latency, and are filled in reverse registration order (head -> neck ->
-backbone), i.e. in the order backward produces gradients, so the first buckets fly while the backbone is still in
-backward.  ``torch.distributed`` is the transport (backend "nccl" is RCCL on ROCm; "gloo" for CPU tests).
+xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound by one link: buckets are kept large (16 MiB on the wire in
+bench.py, ~16 buckets for the 61.9 M parameters) to amortise latency, and are filled in reverse registration order (head -> neck ->
+backbone), i.e. in the order backward produces gradients, so the first buckets fly while the backbone is still in backward.  The
+wire dtype is the parameters' fp32 unless ``bucket_dtype=torch.bfloat16`` is asked for (half the bytes; the reduced buckets are
+widened back into the fp32 ``.grad`` views, the optimizer never sees bf16).  ``torch.distributed`` is the transport (backend "nccl"
+is RCCL on ROCm; "gloo" for CPU tests).
+
+Streams (audited in round 3): weight gradients are computed on the library's low-priority side stream; a
+bucket's gather/narrow launch is enqueued THERE, behind the gradients it reads; its all-reduce is enqueued from the MAIN stream
+one bucket later, after ``wait_event(filled)`` -- so the only cross-stream barrier the process group's stream ever carries waits
+for the main stream's recent past, never for the lagging side stream.
 """
 import contextlib
 
@@ -80,9 +91,11 @@ class GradientReducer:
     ComputeLoss); False leaves the SUM (right for the library's Yolov3Loss, which multiplies its means by the batch size,
     loss/yolov3_loss.py:69-71: under the reference's nn.DataParallel that loss sees the gathered batch of N*b images, whose
     gradient is the sum of the per-rank ``* b`` losses' gradients -- an average would be 1/N of it and make Adam's folded-in weight
-    decay and eps N times stronger; see ``loss_normalisation``).
-    ``bucket_dtype``: dtype the gradients travel in (default: the parameters' own, fp32).  torch.bfloat16 halves the bytes on the
-    xGMI links (124 MB instead of 248 MB per step for YOLOv3); the optimizer reads the bf16 buckets (FusedAdam accepts them).
+    decay and eps N times stronger; ``Yolov3Loss.data_parallel()`` supplies the job-wide match counts).
+    ``bucket_dtype``: dtype the gradients travel in (default: the parameters' own, fp32 -- what the reference's DataParallel
+    reduces).  torch.bfloat16 halves the bytes on the xGMI links (124 MB instead of 248 MB per step for YOLOv3); finish() widens the
+    reduced wire buffers back into the fp32 buckets that ``p.grad`` views, so the optimizer always reads fp32.
+    ``stats()`` reports what the last step did (backend, world size, buckets launched before backward ended, bytes on the wire).
     """
 
     def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True, bucket_dtype=None, world=None):
@@ -95,7 +108,7 @@ class GradientReducer:
         self.buckets, self.where = [], {}
         cur, cur_bytes = [], 0
         for p in order:
-            nbytes = p.numel() * (p.element_size() if bucket_dtype is None else torch.empty(0, dtype=bucket_dtype).element_size())
+            nbytes = p.numel() * (p.element_size() if self.bucket_dtype is None else torch.empty(0, dtype=self.bucket_dtype).element_size())
             if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
                 self._close(cur)
                 cur, cur_bytes = [], 0
@@ -109,7 +122,21 @@ class GradientReducer:
         self.filled = 0               # GPU buckets: filled up to here (their collectives follow one bucket later)
         self._gpu = {}
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.last = {'launched_in_backward': 0, 'collectives': 0}
         self.reset()
+
+    def stats(self):
+        """What the reducer did in the step that finish() last closed: for bench.py's JSON line, so that a driver can check that the
+        backend really saw N ranks and that buckets overlapped the backward pass."""
+        ini = dist.is_available() and dist.is_initialized()
+        return {'backend': dist.get_backend(self.group) if ini else None,
+                'world_size_seen_by_backend': dist.get_world_size(self.group) if ini else 1,
+                'buckets': len(self.buckets),
+                'buckets_launched_before_backward_ended': self.last['launched_in_backward'],
+                'collectives_per_step': self.last['collectives'],
+                'wire_dtype': str(self.buckets[0][3].dtype).replace('torch.', '') if self.buckets else None,
+                'wire_bytes_per_step': sum(b[3].numel() * b[3].element_size() for b in self.buckets) if self.world > 1 else 0,
+                'reduce_op': 'avg' if self.average else 'sum'}
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
@@ -261,6 +288,7 @@ class GradientReducer:
     def finish(self):
         """Launch what is still outstanding (parameters that received no gradient contribute zeros), wait for every
         collective and re-arm for the next step."""
+        self.last = {'launched_in_backward': self.next_launch, 'collectives': 0}
         if self.params and self.params[0].is_cuda:
             from .ops import join_side_stream
             join_side_stream(force=True)
@@ -282,6 +310,7 @@ class GradientReducer:
         self.next_launch = len(self.buckets)
         for bi, h in enumerate(self.handles):
             if h is not None:
+                self.last['collectives'] += 1
                 h[0].wait()
                 flat, wire = self.buckets[bi][0], self.buckets[bi][3]
                 if h[1]:

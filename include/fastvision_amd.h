@@ -115,6 +115,28 @@ int fva_conv_debug_stamps(void* stamps, int32_t rows);
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
  * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
+/* The same with the BatchNorm finalisation INSIDE the launch (round 3; csrc/bn_ticket.h): the waves that write the partial table
+ * draw tickets, the last arriver of each group of rows folds that group in row order (double), the last group folds the groups and
+ * writes what fva_bn_finalize writes -- batch mean / rstd, scale = gamma*rstd, shift = beta - mean*scale, the running statistics
+ * (momentum, unbiased variance) and num_batches_tracked += 1 (classfication/models/darknet53.py:11-12: nn.BatchNorm2d in training
+ * mode).  No second launch; fixed summation order, so results are bit-identical from launch to launch.  Needs Cout % 32 == 0.
+ *   counters:   fva_bn_ticket_counters(fva_conv_stat_blocks(d), Cout) int32, ZERO before the first use; every launch leaves them
+ *               zero again (do not share them between launches that may overlap);
+ *   group_sums: fva_bn_ticket_groups(fva_conv_stat_blocks(d)) x [2][Cout] doubles of scratch (may be NULL for one group);
+ *   stats_partial: plain fva_conv_stat_blocks(d) rows of [2][Cout] floats (no fva_bn_partial_rows() tail needed). */
+typedef struct {
+    int32_t* counters;
+    double* group_sums;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;      /* may be NULL */
+    int64_t* num_batches_tracked;           /* may be NULL */
+    float momentum, eps;
+    float *save_mean, *save_rstd, *scale, *shift;
+} fva_bn_fwd_fin;
+int fva_conv_fwd_bn(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, const fva_bn_fwd_fin* fin,
+                    void* stream);
+int32_t fva_bn_ticket_groups(int32_t rows);
+int64_t fva_bn_ticket_counters(int32_t rows, int32_t C);
 /* Inference form: eval-mode BatchNorm folded into a per-channel affine and SiLU applied in the convolution's epilogue,
  * z = SiLU(conv(x) * scale[c] + shift[c]) (+ residual), written straight into the halo buffer z [B][OH+2p][OW+2p][Cout]
  * (interior by the MFMA kernel, zero border by a small second launch).  residual (optional) has z's geometry.
@@ -132,8 +154,9 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
  * in its epilogue.  dx (incl. the addend) is dz of that producer block z = SiLU(BN(y)) (classfication/models/darknet53.py:28-31,
  * 58-62: what autograd's native_batch_norm_backward + SiLU backward reduce over the batch): per row block and channel the
  * epilogue adds up dU = dz * SiLU'(y * scale + shift) and dU * (y - mean) * rstd from the values it stores, reading y (dense
- * [B*H*W][Cin], the producer's pre-BN output) once.  partial: [fva_conv_dgrad_stat_rows(d)][2][Cin] floats, plain stores, fixed
- * order -- feed it to fva_bn_bwd_finalize in place of fva_bn_silu_bwd_reduce's table.  Valid only when dx IS the whole dz (the
+ * [B*H*W][Cin], the producer's pre-BN output) once.  partial: [fva_bn_partial_rows(fva_conv_dgrad_stat_rows(d))][2][Cin] floats (the rows
+ * beyond fva_conv_dgrad_stat_rows(d) are fva_bn_bwd_finalize's scratch), write-through stores, fixed order -- feed it to
+ * fva_bn_bwd_finalize (partial_rows = the rows allocated) in place of fva_bn_silu_bwd_reduce's table.  Valid only when dx IS the whole dz (the
  * producer's output has no other consumer than this convolution and, through `addend`, the residual identity). */
 typedef struct {
     const void* y;
@@ -143,6 +166,19 @@ typedef struct {
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* fuse, void* stream);
 int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d);
+/* ... and with the producer's BatchNorm-backward finalisation inside the same launch(es) (tickets as in fva_conv_fwd_bn; the parity
+ * launches of a stride-2 layer share one table and one set of counters): writes what fva_bn_bwd_finalize writes -- dgamma, dbeta
+ * (+= when accumulate) and coef[3][Cin] for fva_bn_silu_bwd_apply.  Needs Cin % 32 == 0.  counters / group_sums are sized with
+ * rows = fva_conv_dgrad_stat_rows(d), C = Cin; fuse->partial then needs only those rows.  fin == NULL: fva_conv_dgrad_bnstats. */
+typedef struct {
+    int32_t* counters;
+    double* group_sums;
+    const float* gamma;                     /* of the producer's BatchNorm; its rstd is fuse->rstd */
+    float *dgamma, *dbeta, *coef;
+    int32_t accumulate;
+} fva_bn_bwd_fin;
+int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
+                      const fva_bn_bwd_fuse* fuse, const fva_bn_bwd_fin* fin, void* stream);
 
 /* dw (fp32, OIHW) (+)= sum_pixels dy x.  Deterministic: split-K partial tiles go to `workspace`
  * (fva_conv_wgrad_workspace() bytes) and are reduced in fixed order. */
@@ -170,7 +206,8 @@ int64_t fva_stem_wgrad_mfma_workspace(void);
 /* bf16 training form that never stores conv0's pre-BN output: the four BatchNorm / SiLU passes recompute it on MFMA from the
  * NHWC4 image copy (fva_stem_pack; fva_stem_fwd_workspace() bytes).  mode 0: partial sums of y, y^2 -> part; 1: z = SiLU(BN(y))
  * -> halo buffer out [B][H+2][W+2][32]; 2: partial sums of dU, dU*xhat from dz (dense [B*H*W][32]) -> part; 3: dY -> halo
- * buffer out.  part: fva_stem_fused_blocks() rows of [2][32], reduced by fva_bn_finalize / fva_bn_bwd_finalize. */
+ * buffer out.  part: fva_stem_fused_blocks() rows of [2][32] filled here, ALLOCATED with
+ * fva_bn_partial_rows(fva_stem_fused_blocks()) rows, reduced by fva_bn_finalize / fva_bn_bwd_finalize. */
 int fva_stem_pack(const float* images_nchw, void* images_nhwc4, int64_t bytes, int B, int Cin, int H, int W, void* stream);
 int fva_stem_fused(int mode, const void* images_nhwc4, const float* w_oihw, const void* dz, const float* scale, const float* shift,
                    const float* save_mean, const float* save_rstd, const float* coef, void* out, float* part, int B, int Cin, int H,
@@ -194,9 +231,10 @@ int fva_head_bwd_prepare(int dtype, const float* dhead, const float* grad_scale,
  * num_batches_tracked += 1 (both optional: NULL skips); emit save_mean, save_rstd and the fused
  * scale = gamma*rstd, shift = beta - mean*scale.
  * stats_partial must hold fva_bn_partial_rows(nblocks) rows of [2][C] floats: the conv kernels fill the first
- * nblocks rows; tables of >= 1024 rows are first folded in parallel into the extra rows (scratch). */
+ * nblocks rows; tables of >= 1024 rows are first folded in parallel into the extra rows (scratch).  partial_rows = the rows
+ * the caller allocated: a table that is too short is refused (FVA_ERR_WORKSPACE) instead of written past. */
 int32_t fva_bn_partial_rows(int32_t nblocks);
-int fva_bn_finalize(float* stats_partial, int32_t nblocks, int64_t count, int32_t C,
+int fva_bn_finalize(float* stats_partial, int32_t nblocks, int32_t partial_rows, int64_t count, int32_t C,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_rstd,
                     float* scale, float* shift, void* stream);
@@ -214,8 +252,9 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
 int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
 /* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2.  partial: the table of
  * fva_bn_silu_bwd_reduce or of fva_conv_dgrad_bnstats, ALLOCATED with fva_bn_partial_rows(nblocks) rows: a long table (1024 rows
- * or more) is folded in parallel first, into doubles kept behind the nblocks rows the producer fills. */
-int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int64_t M, int C, const float* gamma,
+ * or more) is folded in parallel first, into doubles kept behind the nblocks rows the producer fills; partial_rows = the rows
+ * allocated (checked: FVA_ERR_WORKSPACE). */
+int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, int64_t M, int C, const float* gamma,
                         const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                         void* stream);
 /* Backward, pass 2: dy = gamma*rstd*(dU - dbeta/n - xhat*dgamma/n) written as halo buffer (border dy_pad). */

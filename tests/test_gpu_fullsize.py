@@ -97,9 +97,11 @@ def test_config3_bf16_full_size_step_vs_oracle(oracle_step):
     rel = np.abs(gnorm - oracle_step['gnorm']) / np.maximum(oracle_step['gnorm'], 1e-12)
     print(f'config3 bf16 B={B} {S}px: head max-err/scale {herr}, loss {loss:.6f} vs oracle {oracle_step["loss"]:.6f} (rel {lrel:.2e}), '
           f'gradient-norm rel dev median {np.median(rel):.2e} p90 {np.quantile(rel, 0.9):.2e} max {rel.max():.2e} ({names[int(rel.argmax())]})')
-    assert lrel < 2e-2
-    assert max(herr) < 1.5e-1                                                   # bf16 activations through 75 layers, random init
-    assert np.median(rel) < 5e-2 and rel.max() < 2.5e-1
+    # gates = about twice what was observed in rounds 2 and 3 (heads 9.6e-2 of the scale, loss 2.9e-5, gradient norms median 3.8e-3 /
+    # max 5.7e-2): a regression of the benchmarked dtype by more than that fails
+    assert lrel < 1e-3
+    assert max(herr) < 1.3e-1                                                   # bf16 activations through 75 layers, random init
+    assert np.median(rel) < 1e-2 and rel.max() < 1.2e-1
 
 
 def test_config3_fp32_full_size_step_vs_oracle(oracle_step):

@@ -91,6 +91,34 @@ def test_graphed_step_is_bit_identical_with_eager(dtype):
     assert torch.equal(a, b)
 
 
+def test_two_graphs_on_one_optimizer_alternate_like_eager():
+    """Two captures on ONE FusedAdam (a second batch size -- the tail batch of an epoch, utils/fit.py:52-66 iterates a loader whose
+    last batch is smaller): each graph owns the pinned words its pointer-table upload re-reads, so alternating replays must equal
+    the same steps issued eagerly, bit for bit.  (Round 2 kept one staging buffer per optimizer: the second capture rewrote the
+    gradient pointers the first graph's Adam launch reads -- ADVICE.)"""
+    import fastvision_amd
+    from fastvision_amd.graphs import GraphedTrainStep
+    from fastvision_amd.synthetic import synthetic_batch
+    big, small = synthetic_batch(3, 128, seed=11), synthetic_batch(2, 128, seed=12)
+    order = [big, small, big, small, small, big]
+    with fastvision_amd.compute_dtype(torch.float32):
+        net, crit, opt = make()
+        want = [eager_step(net, crit, opt, im.to(DEV), tg.to(DEV)) for im, tg in order]
+        want_state = state_of(net, opt)
+        torch.cuda.synchronize()
+        net2, crit2, opt2 = make()
+        g_big = GraphedTrainStep(net2, lambda p, t: crit2(p, t), opt2, big[0].to(DEV), big[1].to(DEV))
+        g_small = GraphedTrainStep(net2, lambda p, t: crit2(p, t), opt2, small[0].to(DEV), small[1].to(DEV))
+        assert g_big._adam_staging[0][0].data_ptr() != g_small._adam_staging[0][0].data_ptr()
+        got = [(g_big if b is big else g_small)(b[0].to(DEV), b[1].to(DEV)).clone() for b in order]
+        got_state = state_of(net2, opt2)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), (a, b)
+    for k in want_state:
+        assert torch.equal(got_state[k], want_state[k]), k
+
+
 def test_device_resident_adam_matches_host_scalar_adam():
     """fva_adam_step_dev (step count / LR in device memory) against fva_adam_step (host scalars): the bias corrections are computed
     by pow() on the device instead of the host's libm, so allow one ulp of the step size (1e-6 relative on the update)."""

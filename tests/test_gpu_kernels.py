@@ -276,7 +276,7 @@ def test_bn_finalize_large_tables(nblocks):
     rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
     nbt = torch.zeros(1, dtype=torch.int64, device=dev())
     mean, rstd, scale, shift = (torch.empty(Cc, device=dev()) for _ in range(4))
-    _lib.call('fva_bn_finalize', ops._p(part), nblocks, count, Cc, ops._p(gamma), ops._p(beta), ops._p(rm), ops._p(rv), ops._p(nbt),
+    _lib.call('fva_bn_finalize', ops._p(part), nblocks, rows, count, Cc, ops._p(gamma), ops._p(beta), ops._p(rm), ops._p(rv), ops._p(nbt),
               0.1, 1e-5, ops._p(mean), ops._p(rstd), ops._p(scale), ops._p(shift), ops._stream())
     s = vals.double().sum(0)
     m = s[0] / count

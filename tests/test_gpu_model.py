@@ -308,9 +308,10 @@ def test_loss_curve_100_steps_bf16_reported(gold_lib, gold_demo):
         assert np.all(np.isfinite(curve)) and curve[-1] < curve[0]
         if surface == 'lib':
             spread = np.max([np.abs(gold_lib[f'g6_curve_t{t}'] - gold) / np.abs(gold) for t in (1, 3, 8)], axis=0)
-            assert rel[:10].max() < 2e-2 and rel.max() <= 2e-2 + 3 * spread.max()
+            # twice the observed 5.4e-3 / 1.8e-2 (the reference's own thread-count spread is 1.66e-2: g6_curve_t{1,3,8})
+            assert spread.max() < 2e-2 and rel[:10].max() < 1.1e-2 and rel.max() < 3.6e-2
         else:
-            assert rel.max() < 6e-2 and rel.mean() < 1e-2
+            assert rel.max() < 6e-2 and rel.mean() < 4.5e-3                      # observed 3.6e-2 (step 4) / 2.1e-3
 
 
 # ------------------------------------------------------------------------------------------------ bf16 path (the bench dtype)
@@ -683,13 +684,14 @@ def _dp_sum_worker(rank, world, port, out):
 def test_data_parallel_reproduces_the_reference_dataparallel_step():
     """Two ranks (one GPU, gloo), each with its own two images: the loss kernel normalises its per-match means by the match counts
     of the WHOLE job and multiplies by the job's batch (fva_yolov3_loss_dp), gradients are SUMMED.  Reference semantics
-    (demos/yolov3_u/train.py:85 nn.DataParallel + loss/yolov3_loss.py:69-71): every replica runs forward on its shard (per-GPU
-    BatchNorm statistics), the outputs are gathered and ONE loss is evaluated on the 4-image batch.  Emulated in-process: two
-    shard forwards, concatenated heads, one loss; parameter gradients must agree to fp32 rounding."""
+    (demos/yolov3_u/train.py:85 nn.DataParallel + demos/yolov3_u/cfg/_fit.py:48-51 + loss/yolov3_loss.py:69-71): every replica runs
+    forward on its shard (per-GPU BatchNorm statistics), the outputs are gathered and ONE loss is evaluated on the 4-image batch.
+    The checker is the CPU ORACLE (round 3; it was an in-process HIP emulation): two shard forwards of oracle.model.LibYolov3 with
+    the same seeded initialisation, concatenated heads, oracle.losses.yolov3_loss once, autograd -- loss and parameter gradients of
+    the two-rank HIP run must agree with it to 1e-3 (fp32)."""
     import socket
     import torch.multiprocessing as mp
-    import fastvision_amd
-    from fastvision_amd import ops, parallel
+    from oracle import train as otrain
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     out = mgr.dict()
@@ -697,22 +699,48 @@ def test_data_parallel_reproduces_the_reference_dataparallel_step():
     (g0, total0, share0), (g1, total1, share1) = out[0], out[1]
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
-    prev = ops.set_wgrad_side_stream(False)      # one weight receives two gradient contributions inside ONE backward pass here
-    try:
-        with fastvision_amd.compute_dtype(torch.float32):
-            net, crit = lib_model(seed=20220504), lib_loss()
-            images, tg = synthetic_batch(4, 64, seed=77)
-            preds = [net(images[r * 2:(r + 1) * 2].to(DEV)) for r in range(2)]
-            gathered = [torch.cat([preds[0][l], preds[1][l]], 0) for l in range(3)]
-            loss = crit(gathered, tg.to(DEV))
-            loss.backward()
-            want = {k: p.grad.detach().cpu() for k, p in list(net.named_parameters())[::23]}
-    finally:
-        ops.set_wgrad_side_stream(prev)
-    assert abs(total0 - float(loss)) <= 1e-5 * abs(float(loss)) and total0 == total1 and share0 != share1
+    ref, ref_crit = otrain.make_library(20220504)
+    images, tg = synthetic_batch(4, 64, seed=77)
+    preds = [ref(images[r * 2:(r + 1) * 2]) for r in range(2)]          # what nn.DataParallel's replicas compute
+    gathered = [torch.cat([preds[0][l], preds[1][l]], 0) for l in range(3)]
+    loss = ref_crit(gathered, tg)                                       # ONE loss on the gathered batch
+    loss.backward()
+    want = {k: p.grad.detach() for k, p in ref.named_parameters()}
+    assert abs(total0 - float(loss)) <= 1e-4 * abs(float(loss)) and total0 == total1 and share0 != share1
+    worst = 0.0
     for k in g0:
         err = ((g0[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-12)).item()
-        assert err < 1e-4, f'{k}: {err}'
+        worst = max(worst, err)
+        assert err < 1e-3, f'{k}: {err}'
+    print(f'two ranks vs the oracle on the gathered batch: loss {total0:.6f} vs {float(loss):.6f}, worst gradient deviation {worst:.2e}')
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The REAL `python bench.py --gpus 2` path -- the parent starts torch.distributed.run with two ranks of itself before it touches
+    the GPU (the reference wraps its model in nn.DataParallel, demos/yolov3_u/train.py:85) -- on the one GPU of this box, with the
+    collectives over gloo (RCCL refuses two ranks on one device): rendezvous, broadcast, job-wide loss normalisation, gradient
+    buckets launched from the autograd hooks, FusedAdam, the JSON contract incl. the `dp` block a driver checks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['FVA_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                        '--batch', '8', '--size', '320'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    dp = d['dp']
+    print(f"bench --gpus 2 over gloo on one GPU: {d['value']} img/s, {d['ms_per_step']} ms/step, loss {d['loss']}, dp {dp}")
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 16
+    assert np.isfinite(d['loss']) and d['value'] > 0
+    assert dp['backend'] == 'gloo' and dp['world_size_seen_by_backend'] == 2 and dp['reduce_op'] == 'sum' and dp['wire_dtype'] == 'float32'
+    assert dp['collectives_per_step'] == dp['buckets'] and dp['wire_bytes_per_step'] == 4 * 61949149
+    assert dp['buckets_launched_before_backward_ended'] >= dp['buckets'] - 2       # all but the last buckets flew during backward
+    assert dp['parameters_identical_across_ranks'] is True
 
 
 def _nccl_worker(rank, world, port, out):

@@ -287,3 +287,21 @@ def test_faster_rcnn_fit_loop_contract(tmp_path, monkeypatch):
     assert abs(opt.param_groups[0]['lr'] - 0.1) < 1e-12                               # epoch 9: divided by ten
     assert (tmp_path / '8.pth').exists() and (tmp_path / '9.pth').exists()
     assert set(torch.load(tmp_path / '9.pth')) == {'w'}
+
+
+def test_rpn_sample_refuses_a_permutation_that_does_not_fit():
+    """Round 2 hit a GPU exception (HSA 0x1016 inside ATen's index kernel, gpurun_out/r2f/cfg5.log) when a sampling permutation
+    drawn for the oracle's candidate list indexed past the HIP path's shorter list (demos/faster_rcnn/models/rpn.py:279-290 draws
+    its own torch.randperm): rpn_sample range-checks a given permutation on the host, before any indexing kernel runs."""
+    import pytest
+    import torch
+    from fastvision_amd import rpn_ops
+    lab = torch.tensor([0, -1, -1, 1, -2, -1, 0])                   # 3 positives (>= 0), 3 negatives (-1), 1 ignored
+    pos, neg = rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([1, 0, 2]), torch.tensor([2, 1, 0]))
+    assert pos.tolist() == [3, 0] and neg.tolist() == [5, 2]
+    with pytest.raises(ValueError, match='positive permutation'):
+        rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([1]), torch.tensor([2, 1, 0]))             # too short for the 2 to draw
+    with pytest.raises(ValueError, match='negative permutation'):
+        rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([1, 0, 2]), torch.tensor([3, 1, 0]))       # 3 indexes past the 3 candidates
+    with pytest.raises(ValueError, match='positive permutation'):
+        rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([-1, 0, 2]), torch.tensor([2, 1, 0]))      # negative index

@@ -163,3 +163,6 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['dry_run'] is True and d['reduced_gradients_ok'] is True and d['n_params'] == 61949149
     assert d['config']['parallelism'] == 'dp2' and d['value'] is None
+    dp = d['dp']            # what the reducer saw: the backend's world size, the wire, one collective per bucket
+    assert dp['backend'] == 'gloo' and dp['world_size_seen_by_backend'] == 2 and dp['wire_dtype'] == 'float32' and dp['reduce_op'] == 'sum'
+    assert dp['collectives_per_step'] == dp['buckets'] > 1 and dp['wire_bytes_per_step'] == 4 * 61949149

@@ -19,7 +19,7 @@ from fastvision_amd.demos.faster_rcnn.models import Faster_Rcnn
 DEV = 'cuda:0'
 
 
-def main(steps=None, warmup=3, cpu_baseline=True):
+def main(steps=None, warmup=3, cpu_baseline=True, emit=True):
     if steps is None:
         steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     B, H, W, NC = 4, 800, 1333, 20
@@ -112,7 +112,8 @@ def main(steps=None, warmup=3, cpu_baseline=True):
                    '(each step reads sample counts back like the reference)'}
     if cpu is not None:
         out['cpu_baseline'] = cpu
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
     return out
 
 

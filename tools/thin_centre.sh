@@ -1,0 +1,4 @@
+for sh in "32 32 64 320 320 3 1" "32 64 128 160 160 3 1" "32 32 64 640 640 3 2" "32 64 128 320 320 3 2" "32 128 256 160 160 3 2"; do
+  python tools/bench_conv.py $sh 10
+  FVA_TAP_CENTRE=1 python tools/bench_conv.py $sh 10
+done
