@@ -78,6 +78,7 @@ PROTOTYPES = {
     'fva_side_stream_fork': (_I, [_P, C.POINTER(C.c_void_p)]),
     'fva_side_stream_join': (_I, [_P]),
     'fva_conv_debug_stamps': (_I, [_P, _I]),
+    'fva_conv_patch_kernel': (_I, [_I]),
     'fva_profile_stop': (_I, [_P, _P, _P, _I]),
     'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
     'fva_conv_packed_elems': (_L, [_D, _I]),
@@ -160,7 +161,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_bn_ticket_groups', 'fva_bn_ticket_counters', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_conv_patch_kernel', 'fva_bn_ticket_groups', 'fva_bn_ticket_counters', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

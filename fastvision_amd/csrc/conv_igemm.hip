@@ -55,6 +55,7 @@ struct IgemmParams {
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
     int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
+    int pt_tiles, pt_tpb;           //   tiles of the launch, consecutive tiles per block (the resident weights are staged once per block)
     FastDiv pt_div_tx, pt_div_img;  //   divisions by pt_tx and pt_tx * pt_ty
     BnTicket tk;         // mode != 0: the statistics table (stats / bnb_part) is folded and finalised inside this launch (bn_ticket.h)
 };
@@ -739,23 +740,22 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     constexpr int WBUF_BYTES = (RESIDENT ? 9 : 2) * WSTEP_BYTES;
     constexpr int BM = 256, NT = 256, NTILE = BN / 16, KS = CS / 32;
     constexpr int PITCH = BN * 2 + 16, TILE_BYTES = BM * PITCH;
-    constexpr int COEF0 = TILE_BYTES > PATCH_BYTES + WBUF_BYTES ? TILE_BYTES : PATCH_BYTES + WBUF_BYTES;   // BNB coefficient table: clear of both uses
+    // resident weights live across the block's tiles: the epilogue's tile may alias the patch, not them; a ring is re-streamed per tile
+    constexpr int WOFF = RESIDENT && TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
+    constexpr int COEF0 = TILE_BYTES > WOFF + WBUF_BYTES ? TILE_BYTES : WOFF + WBUF_BYTES;   // BNB coefficient table: clear of both uses
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch = smem;
-    char* const wbuf = smem + PATCH_BYTES;
+    char* const wbuf = smem + WOFF;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int b = (int)fd_div((uint32_t)tile, p.pt_div_img);
-    const int trem = tile - b * (p.pt_tx * p.pt_ty);
-    const int ty = (int)fd_div((uint32_t)trem, p.pt_div_tx), tx = trem - ty * p.pt_tx;
+    const int tile0 = ((xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3)) * (RESIDENT ? p.pt_tpb : 1);
     const int Hp = p.in_img / p.in_row, Wp = p.in_row;
-    const int yorg = p.y0 + ty * TH, xorg = p.x0 + tx * TW;            // patch origin in the padded input
     float* coef_tab = (float*)(smem + COEF0);
     if constexpr (EPI == EPI_BNB) bnb_fill_lds<BN, NT>(p, coef_tab, tid, 0);   // before the first LDS-DMA; read in the epilogue
+    int b = 0, ty = 0, tx = 0, yorg = 0, xorg = 0;                     // the current tile (set at the top of the tile loop)
 
     // swizzle of a row (pixel or weight row) of the LDS images: chunk c of row r sits in slot c ^ swz(r)
     auto swz = [](int r) { return CS == 64 ? (r >> 1) & 7 : (-(r >> 2)) & 3; };
@@ -794,14 +794,10 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     };
 
     f32x4 acc[4][NTILE];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NTILE; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's A rows: wave w owns patch rows 2w, 2w + 1; tile mt = row (mt >> 1), x half (mt & 1); tap (dy, dx) adds dy * PW + dx
     int pix0[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) pix0[mt] = (2 * w + (mt >> 1)) * PW + (mt & 1) * 16 + r16;
+    int opq = 0;   // re-made opaque in every tile: the 72 + fragment addresses of a tile are then computed where they are used, not
+                   // hoisted out of the tile loop (as loop invariants they cost 150-280 spilled registers)
     auto compute = [&](int tap, const char* wb) {
         const int tapoff = (tap / 3) * PW + (tap % 3);
 #pragma unroll
@@ -814,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
             }
 #pragma unroll
             for (int nt = 0; nt < NTILE; ++nt) {
-                const int n = nt * 16 + r16;
+                const int n = nt * 16 + r16 + opq;
                 bfr[nt] = *(const bf16x8*)(wb + n * PIXB + (((ks * 4 + g) ^ swz(n)) << 4));
             }
 #pragma unroll
@@ -825,9 +821,32 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     };
 
     if constexpr (RESIDENT) {
-        stage_patch(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) stage_w(t, wbuf + t * WSTEP_BYTES);
+    }
+    // only the resident-weight forms loop over tiles (a ring re-streams its weights per tile anyway, and inside a loop its per-step
+    // staging addresses are hoisted as loop invariants: 120-240 spilled registers)
+#pragma unroll 1
+    for (int it = 0; it < (RESIDENT ? p.pt_tpb : 1); ++it) {
+    const int tile = tile0 + it;
+    if (tile >= p.pt_tiles) break;                                     // block-uniform
+    b = (int)fd_div((uint32_t)tile, p.pt_div_img);
+    {
+        const int trem = tile - b * (p.pt_tx * p.pt_ty);
+        ty = (int)fd_div((uint32_t)trem, p.pt_div_tx);
+        tx = trem - ty * p.pt_tx;
+    }
+    yorg = p.y0 + ty * TH;                                             // patch origin in the padded input
+    xorg = p.x0 + tx * TW;
+    asm volatile("" : "+v"(opq));
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) pix0[mt] = (2 * w + (mt >> 1)) * PW + (mt & 1) * 16 + r16 + opq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RESIDENT) {
+        stage_patch(0);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -916,13 +935,19 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     if constexpr (EPI == EPI_STATS) {
         if (p.tk.mode && p.stats != nullptr && w < BN / 32 && w * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), tile, w, lane);
     }
+    __syncthreads();   // the next tile's patch lands where this tile's epilogue read
+    }
 }
 
 // Layers the patch kernel serves (bf16, 3x3, stride 1): reduction channels C in {32, 64, 128}, outputs N in {32, 64, 128}, at most
 // C x N = 8192, on maps of at least 64 x 64 (below that the 8 x 32 patches overhang too much).  FVA_PCONV=0 switches it off.
+int g_pconv = -1;   // -1: read FVA_PCONV on first use; fva_conv_patch_kernel() sets it
 inline bool pconv_enabled() {
-    static bool v = [] { const char* e = getenv("FVA_PCONV"); return !e || atoi(e) != 0; }();
-    return v;
+    if (g_pconv < 0) {
+        const char* e = getenv("FVA_PCONV");
+        g_pconv = (!e || atoi(e) != 0) ? 1 : 0;
+    }
+    return g_pconv != 0;
 }
 inline bool use_pconv(int dtype, int ksize, int stride, int C, int N, int H, int W) {
     if (!pconv_enabled() || dtype != FVA_BF16 || ksize != 3 || stride != 1 || H < 64 || W < 64) return false;
@@ -931,18 +956,25 @@ inline bool use_pconv(int dtype, int ksize, int stride, int C, int N, int H, int
 inline int pconv_tiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 32); }
 
 template <int CS, int BN, int NSL, int EPI>
-int launch_pconv_one(const IgemmParams& p, int tiles, hipStream_t s) {
+int launch_pconv_one(const IgemmParams& p0, int tiles, hipStream_t s) {
     constexpr int PIXB = CS * 2, PPI = 1024 / PIXB, PATCH_BYTES = ((340 + PPI - 1) / PPI) * 1024, WSTEP = BN * PIXB;
     constexpr bool RESIDENT = NSL == 1 && 9 * WSTEP <= 36 * 1024;
     constexpr int WBUF = (RESIDENT ? 9 : 2) * WSTEP, TILE = 256 * (BN * 2 + 16);
-    constexpr int smem = (TILE > PATCH_BYTES + WBUF ? TILE : PATCH_BYTES + WBUF) + (EPI == EPI_BNB ? 4 * BN * 4 : 0);
+    constexpr int WOFF = RESIDENT && TILE > PATCH_BYTES ? TILE : PATCH_BYTES;
+    constexpr int smem = (TILE > WOFF + WBUF ? TILE : WOFF + WBUF) + (EPI == EPI_BNB ? 4 * BN * 4 : 0);
     static_assert(smem <= 80 * 1024, "two blocks per CU");
+    // consecutive tiles per block: resident weights (36 KiB) cost more L2 -> LDS bytes than the patch itself when re-staged per tile
+    static const int tpb_env = [] { const char* e = getenv("FVA_PCONV_TPB"); return e ? atoi(e) : 0; }();
+    IgemmParams p = p0;
+    p.pt_tiles = tiles;
+    p.pt_tpb = RESIDENT ? (tpb_env > 0 ? tpb_env : 2) : 1;     // measured 1 / 2 / 4 / 8 on 32 -> 64 at 320^2: fwd 253 / 235 / 260 / 261 us, dgrad 218 / 209 / 214 / 224
+    const int blocks = cdiv(tiles, p.pt_tpb);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)pconv_kernel<CS, BN, NSL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((pconv_kernel<CS, BN, NSL, EPI>), dim3(tiles), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((pconv_kernel<CS, BN, NSL, EPI>), dim3(blocks), dim3(256), smem, s, p);
     FVA_LAUNCH_CHECK("pconv_kernel");
     return FVA_OK;
 }
@@ -1639,6 +1671,12 @@ int fva_conv_set_workspace(void* ws, int64_t bytes) {
 long long* fva_debug_stamps_ptr() { return g_stamps; }
 int fva_debug_stamps_rows() { return g_stamp_rows; }
 extern "C" {
+
+int fva_conv_patch_kernel(int on) {
+    const int prev = pconv_enabled() ? 1 : 0;
+    g_pconv = on ? 1 : 0;
+    return prev;
+}
 
 int fva_conv_debug_stamps(void* stamps, int32_t rows) {
     if (stamps && rows < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_debug_stamps: rows must be >= 1");

@@ -110,6 +110,11 @@ int64_t fva_conv_streamk_timeouts(void);
  * 256x64 kernels stamp too, eight wall-clock values per block: entry, first DMA issued, first k-tile landed, k loop done, tile staged
  * in LDS, exit, source rows ready, epilogue operands requested (tools/tile_timing.py pw). */
 int fva_conv_debug_stamps(void* stamps, int32_t rows);
+/* The thin 3x3 stride-1 bf16 layers (reduction channels <= 128, outputs <= 128, maps of 64 x 64 and more) run on the patch kernel
+ * (conv_igemm.hip pconv_kernel: the input patch of an 8 x 32 output tile is staged once for the nine taps).  This switches it off /
+ * on for the process (default on; env FVA_PCONV=0) and returns the previous setting: fva_conv_stat_blocks / fva_conv_dgrad_stat_rows
+ * follow the setting, so do not change it between sizing a table and the launch that fills it. */
+int fva_conv_patch_kernel(int on);
 
 /* y[B*OH*OW][Cout] = conv(x) (dense, dtype).  If stats_partial != NULL also writes per-row-block
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of

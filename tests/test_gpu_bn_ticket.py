@@ -34,6 +34,7 @@ FWD_CASES = [
     (2, 32, 64, 64, 64, 3, 1),        # half-row k-tiles (Cin = 32), thin tile, 32 rows
     (3, 64, 96, 20, 20, 3, 2),        # stride 2, Cout = 96: three slices, column tail of the 128 tile
     (8, 256, 512, 64, 64, 3, 1),      # 8-phase 256x256 kernel (bf16): 128 row blocks x 2 column blocks
+    (2, 64, 128, 72, 64, 3, 1),       # patch kernel (bf16): 36 patches
 ]
 
 
@@ -112,6 +113,7 @@ BWD_CASES = [
     (2, 64, 128, 16, 16, 3, 2),      # stride 2, thin: two paired launches (N' = 2 * Cin: two table rows per block)
     (2, 32, 64, 32, 32, 3, 2),       # the same with Cin = 32: a slice is one pixel parity
     (8, 256, 512, 64, 64, 3, 1),     # 8-phase 256x256 kernel (bf16)
+    (2, 64, 128, 72, 64, 3, 1),      # patch kernel (bf16): reduction over 128 channels in two slices, N = 64
 ]
 
 

@@ -47,6 +47,11 @@ CONV_CASES = [
     (1, 256, 256, 13, 13, 3, 1),     # two column blocks, several k-tiles per tap
     (3, 64, 128, 8, 12, 3, 2),       # stride 2, non-square
     (1, 384, 128, 6, 6, 1, 1),       # concat-style channel count
+    # thin 3x3 stride-1 layers on maps >= 64 x 64: the patch kernel (bf16; fp32 stays on the implicit-GEMM kernels)
+    (2, 32, 64, 64, 96, 3, 1),       # forward C = 32 / N = 64 (resident weights), dgrad C = 64 / N = 32; whole 8 x 32 patches
+    (1, 64, 128, 70, 72, 3, 1),      # forward C = 64 / N = 128 (weight ring), dgrad C = 128 / N = 64 (two channel slices); patches overhang both ways
+    (1, 128, 64, 66, 64, 3, 1),      # forward two channel slices, dgrad the weight ring
+    (1, 64, 64, 64, 65, 3, 1),       # C = N = 64
 ]
 
 
@@ -443,3 +448,58 @@ def test_gather_cast_fills_a_gradient_bucket(wire):
             assert torch.isnan(got.float()).all(), i
         else:
             assert torch.equal(got, t.to(wire)), i
+
+
+@pytest.mark.parametrize('case', [(2, 32, 64, 64, 96), (1, 64, 128, 70, 72), (1, 128, 64, 66, 64), (1, 64, 64, 64, 65)])
+def test_patch_kernel_against_the_implicit_gemm_kernels(case):
+    """pconv_kernel (thin 3x3 stride-1 bf16 layers: the patch of an 8 x 32 output tile staged once for the nine taps) against the
+    implicit-GEMM kernels it replaces on the same inputs, switched in-process (fva_conv_patch_kernel): forward tile + BatchNorm
+    statistics, dgrad with the residual addend, dgrad with the fused BatchNorm-backward statistics.  Same products, another summation
+    order: outputs agree to bf16 rounding of the stored value (one ulp = 2^-8 relative), column sums of the statistics to 1e-4."""
+    from fastvision_amd import _lib, ops
+    B, Cin, Cout, H, W = case
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(dev())
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    keep, xptr, xpad = halo(x, dtype)
+    dyk, dyptr, dypad = halo(gy, dtype)
+    d = _lib.ConvDesc(ops._code(dtype), B, H, W, Cin, Cout, 3, 1, xpad, 1)
+    wf, wd = ops.packed_weights(w, d, dtype, cache=False)
+    M = B * H * W
+    add = torch.randn(B, H, W, Cin, generator=g).to(dev()).to(dtype)
+    yprod = (torch.randn(M, Cin, generator=g) * 1.5 + 0.3).to(dev()).to(dtype)
+    v4 = [(torch.rand(Cin, generator=g) + 0.5).to(dev()) for _ in range(4)]
+    out = {}
+    prev = lib.fva_conv_patch_kernel(1)
+    try:
+        for on in (0, 1):
+            lib.fva_conv_patch_kernel(on)
+            nblk = lib.fva_conv_stat_blocks(C.byref(d))
+            y = torch.empty((M, Cout), dtype=dtype, device=dev())
+            stats = torch.full((nblk, 2, Cout), float('nan'), device=dev())
+            _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(xptr), ops._p(wf), ops._p(y), ops._p(stats), ops._stream())
+            dx = torch.empty((B, H, W, Cin), dtype=dtype, device=dev())
+            _lib.call('fva_conv_dgrad', C.byref(d), C.c_void_p(dyptr), ops._p(wd), ops._p(dx), ops._p(add), ops._stream())
+            rows = lib.fva_conv_dgrad_stat_rows(C.byref(d))
+            part = torch.full((lib.fva_bn_partial_rows(rows), 2, Cin), float('nan'), device=dev())
+            fs = _lib.BnBwdFuse(yprod.data_ptr(), v4[0].data_ptr(), v4[1].data_ptr(), v4[2].data_ptr(), v4[3].data_ptr(), part.data_ptr())
+            dx2 = torch.empty_like(dx)
+            _lib.call('fva_conv_dgrad_bnstats', C.byref(d), C.c_void_p(dyptr), ops._p(wd), ops._p(dx2), ops._p(add), C.byref(fs), ops._stream())
+            torch.cuda.synchronize()
+            assert torch.isfinite(stats).all() and torch.isfinite(part[:rows]).all()
+            out[on] = (y.float(), stats.double().sum(0), dx.float(), dx2.float(), part[:rows].double().sum(0), nblk, rows)
+    finally:
+        lib.fva_conv_patch_kernel(prev)
+    (y0, s0, dx0, dxb0, p0, n0, r0), (y1, s1, dx1, dxb1, p1, n1, r1) = out[0], out[1]
+    tiles = B * ((H + 7) // 8) * ((W + 31) // 32)
+    assert n1 == tiles and r1 == tiles                                       # the patch kernel's tables: one row per 8 x 32 patch
+    for a, b, what in ((y1, y0, 'forward'), (dx1, dx0, 'dgrad + addend'), (dxb1, dxb0, 'dgrad + statistics')):
+        # the fp32 sums differ in their last bits, so some stored values round to the neighbouring bf16 (2^-8 relative; the addend
+        # path rounds twice): at most a bf16 ulp or two of the tensor's scale anywhere, a small fraction of an ulp on average
+        assert rel_err(a, b) < 1e-2, f'{what}: {rel_err(a, b)}'
+        assert ((a - b).abs().mean() / b.abs().mean()).item() < 2e-3, what
+    assert torch.equal(dx1, dxb1)
+    assert rel_err(s1, s0) < 1e-4 and rel_err(p1, p0) < 2e-3
