@@ -108,6 +108,8 @@ struct FvaProfileSpan {
     ~FvaProfileSpan();
 };
 
+hipStream_t fva_side_stream_peek();   // errors.hip: the low-priority side stream, NULL before the first fork
+
 // diagnostic stamp buffer shared by the 8-phase kernels (set by fva_conv_debug_stamps)
 long long* fva_debug_stamps_ptr();
 int fva_debug_stamps_rows();

@@ -72,8 +72,12 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <typename T>
+// THIN (bf16, Cout <= 64): the four waves split the tile's 128 COLUMNS (32 each) and all take rows 0..63, instead of 2 x 2 waves of
+// 64 x 64 -- with 64 output channels the two lower waves of the square arrangement multiplied rows that do not exist (the
+// 32 -> 64 layers at 320^2 executed 2.7 x their useful MFMAs and ran at 276 TFLOP/s).
+template <typename T, bool THIN = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+    static_assert(!THIN || sizeof(T) == 2, "the thin arrangement is a bf16 variant");
     constexpr bool IS_BF16 = sizeof(T) == 2;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int TILE = 16 * EPC;  // channels per tile side: 128 bf16 / 64 f32 (256-byte rows)
@@ -82,7 +86,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = THIN ? 0 : w >> 1, wc = THIN ? w : w & 1;
+    constexpr int NTW = 4, CTW = THIN ? 2 : 4;     // 16 x 16 accumulator tiles per wave along n / along the columns
+    constexpr int WCOLS = CTW * 16;                // columns per wave
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
@@ -182,17 +188,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         // 32-pixel half of the tile go into the instruction's immediate offset, so the loop does no address math
         const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
         const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
-        uint32_t ra[2][4], rb[2][4];
+        uint32_t ra[2][NTW], rb[2][CTW];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int row = 8 * g + 4 * hh + q;                 // + 32 * kk
             const int fr = (q << 2) | ((2 * g + hh) & 3);       // swizzle of that row (unchanged by + 32)
             const int rbase = row * 256 + 8 * (pp & 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ra[hh][t] = lds0 + rbase + (((wr * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
-                rb[hh][t] = lds0 + rbase + (((wc * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
-            }
+            for (int t = 0; t < NTW; ++t) ra[hh][t] = lds0 + rbase + (((wr * 8 + t * 2 + (pp >> 1)) ^ fr) << 4);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) rb[hh][t] = lds0 + rbase + (((wc * (WCOLS / 8) + t * 2 + (pp >> 1)) ^ fr) << 4);
         }
         // transposed read: lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a 4-row x 16-column
         // block and receives column (lane&15) of the 4 rows; two reads (k = 8g+0..3, 8g+4..7) make one MFMA fragment
@@ -202,22 +207,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             else wait_vm0();
             __builtin_amdgcn_s_barrier();
             if (st >= 1 && st + 1 < steps) issue_step(decltype(stage_tag)::value ^ 1);
-            bf16x8 af[2][4], bfr[2][4];
-#define FVA_TR_PAIR(KK, TT)                                                                                            \
-    af[KK][TT] = cat8(tr_read<SO + KK * 8192>(ra[0][TT]), tr_read<SO + KK * 8192>(ra[1][TT]));                           \
-    bfr[KK][TT] = cat8(tr_read<SO + OP_BYTES + KK * 8192>(rb[0][TT]), tr_read<SO + OP_BYTES + KK * 8192>(rb[1][TT]));
-            FVA_TR_PAIR(0, 0) FVA_TR_PAIR(0, 1) FVA_TR_PAIR(0, 2) FVA_TR_PAIR(0, 3)
-            FVA_TR_PAIR(1, 0) FVA_TR_PAIR(1, 1) FVA_TR_PAIR(1, 2) FVA_TR_PAIR(1, 3)
-#undef FVA_TR_PAIR
+            bf16x8 af[2][NTW], bfr[2][CTW];
+#define FVA_TR_A(KK, TT) af[KK][TT] = cat8(tr_read<SO + KK * 8192>(ra[0][TT]), tr_read<SO + KK * 8192>(ra[1][TT]));
+#define FVA_TR_B(KK, TT) bfr[KK][TT] = cat8(tr_read<SO + OP_BYTES + KK * 8192>(rb[0][TT]), tr_read<SO + OP_BYTES + KK * 8192>(rb[1][TT]));
+            FVA_TR_A(0, 0) FVA_TR_B(0, 0) FVA_TR_A(0, 1) FVA_TR_B(0, 1) FVA_TR_A(0, 2) FVA_TR_A(0, 3)
+            if constexpr (!THIN) { FVA_TR_B(0, CTW - 2) FVA_TR_B(0, CTW - 1) }
+            FVA_TR_A(1, 0) FVA_TR_B(1, 0) FVA_TR_A(1, 1) FVA_TR_B(1, 1) FVA_TR_A(1, 2) FVA_TR_A(1, 3)
+            if constexpr (!THIN) { FVA_TR_B(1, CTW - 2) FVA_TR_B(1, CTW - 1) }
+#undef FVA_TR_A
+#undef FVA_TR_B
             if (st >= 1 && st + 2 < steps) decode_step(st + 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                    for (int ct = 0; ct < CTW; ++ct)
                         acc16[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][nt], bfr[kk][ct], acc16[nt][ct], 0, 0, 0);
         };
         for (int st = 0; st < steps; st += 2) {
@@ -262,11 +269,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     if constexpr (IS_BF16) {
         const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) store(n0 + wr * 64 + nt * 16 + g * 4 + j, wc * 64 + ct * 16 + r, acc16[nt][ct][j]);
+                for (int j = 0; j < 4; ++j) store(n0 + wr * 64 + nt * 16 + g * 4 + j, wc * WCOLS + ct * 16 + r, acc16[nt][ct][j]);
     } else {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -619,6 +626,14 @@ struct WgradPlan {
     int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW, tpt, ngroups;
 };
 
+// FVA_WGRAD_THIN=0: layers with Cout <= 64 keep the square 2 x 2 wave arrangement (A/B aid)
+inline bool wgrad_thin_enabled() {
+    static bool v = [] {
+        const char* e = getenv("FVA_WGRAD_THIN");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
 // FVA_WGRAD8=0 keeps every layer on the 128x128 kernel (A/B aid)
 inline bool wgrad8_enabled() {
     static bool v = [] {
@@ -638,7 +653,11 @@ inline bool use_wgrad8(const fva_conv_desc* d) {
     return M * units >= 24ll * 64 * 256;
 }
 
-int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
+// beside: the launch goes to the library's low-priority side stream and shares the chip with the rest of the backward pass: planned
+// for HALF the resident block slots, its fewer, longer blocks leave CUs to the launch stream and write half the slab bytes.  Measured
+// in the whole step (tools/wgrad_slots.sh, same box, after the patch kernel): 29.94 ms with 128 / 256 slots against 30.2 with
+// 256 / 512; alone on a stream the same plan is slower (33.8 against 31.0 ms single-stream), hence the switch.
+int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl, bool beside = false) {
     pl.tile = d->dtype == FVA_BF16 ? (use_wgrad8(d) ? 256 : 128) : 64;
     pl.OH = (d->H - 1) / d->stride + 1;
     pl.OW = (d->W - 1) / d->stride + 1;
@@ -662,9 +681,9 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl) {
     // the 256x256 8-phase kernel runs one block per CU (256 slots) at ~4.3 TFLOP/s per block
     // FVA_WGRAD_SLOTS8 / FVA_WGRAD_SLOTS (experiment): plan for fewer resident blocks than the chip holds -- fewer, longer blocks and
     // less slab traffic, leaving CUs to the launch stream when the weight gradients run beside it
-    static const int slots8 = [] { const char* e = getenv("FVA_WGRAD_SLOTS8"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
-    static const int slots4 = [] { const char* e = getenv("FVA_WGRAD_SLOTS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-    const int slots = pl.tile == 256 ? slots8 : slots4;
+    static const int slots8 = [] { const char* e = getenv("FVA_WGRAD_SLOTS8"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    static const int slots4 = [] { const char* e = getenv("FVA_WGRAD_SLOTS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int slots = pl.tile == 256 ? (slots8 ? slots8 : beside ? 128 : 256) : (slots4 ? slots4 : beside ? 256 : 512);
     const double t_full = 2.0 * pl.M * pl.tile * pl.tile / (pl.tile == 256 ? 4.3e12 : 1.6e12);
     const double t_slab = (double)per * 2.0 / 3.0e12 + 0.05e-6;
     int ks = 1;
@@ -685,9 +704,10 @@ extern "C" {
 
 int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d) {
     if (!d) return 0;
-    WgradPlan pl;
-    plan_wgrad(d, pl);
-    return (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
+    WgradPlan pl, pb;
+    plan_wgrad(d, pl, false);
+    plan_wgrad(d, pb, true);          // whichever stream the launch will be given
+    return (int64_t)(pl.ksplit > pb.ksplit ? pl.ksplit : pb.ksplit) * pl.ntaps * d->Cout * d->Cin * 4;
 }
 
 int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
@@ -705,7 +725,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         (int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cout * esz >= (1ll << 32))
         return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
-    plan_wgrad(d, pl);
+    plan_wgrad(d, pl, stream != nullptr && (hipStream_t)stream == fva_side_stream_peek());
     FvaProfileSpan span(2 | (d->ksize << 8), 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     const int64_t need = (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
     if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_conv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
@@ -750,7 +770,9 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         p.stamps = fva_debug_stamps_ptr();
         p.stamp_rows = fva_debug_stamps_rows();
         hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
-    } else if (d->dtype == FVA_BF16)
+    } else if (d->dtype == FVA_BF16 && d->Cout <= 64 && wgrad_thin_enabled())
+        hipLaunchKernelGGL((wgrad_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, p);
+    else if (d->dtype == FVA_BF16)
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);
     else
         hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), smem, s, p);
@@ -826,7 +848,10 @@ int fva_stem_wgrad_mfma(const void* img4, const void* dy_halo, float* dw_raw, vo
     p.ngroups = 1;
     FvaProfileSpan span(2 | (3 << 8), 2.0 * M * 32.0 * 27.0, (hipStream_t)stream);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(ksplit), dim3(256), 2 * 2 * 64 * 256, s, p);
+    if (wgrad_thin_enabled())
+        hipLaunchKernelGGL((wgrad_kernel<bf16_t, true>), dim3(ksplit), dim3(256), 2 * 2 * 64 * 256, s, p);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(ksplit), dim3(256), 2 * 2 * 64 * 256, s, p);
     FVA_LAUNCH_CHECK("wgrad_kernel");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((32 * 16 + 63) / 64), dim3(256), 0, s, (const float*)workspace, dw_raw, 32, 16, 3, ksplit, 0);
     FVA_LAUNCH_CHECK("wgrad_reduce_kernel");

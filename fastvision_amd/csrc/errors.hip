@@ -100,6 +100,9 @@ extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
     return FVA_OK;
 }
 
+// the library's side stream, or NULL before the first fork (conv_wgrad.hip plans its split-K for the stream it is launched on)
+hipStream_t fva_side_stream_peek() { return g_side; }
+
 extern "C" int fva_side_stream_join(void* main_stream) {
     if (!g_side) return FVA_OK;
     hipEvent_t e = side_event();

@@ -2,8 +2,11 @@
 
 Every function runs the HIP kernels ``fva_iou_pairwise`` / ``fva_iou_batch`` (csrc/loss.hip) with the reference's
 quirks kept (eps inside the height factor of the pairwise IoU, DIoU "+" sign, GIoU_batch "+" sign, CIoU alpha
-constant).  Pairwise functions are differentiable w.r.t. their FIRST argument.  CPU tensors and numpy arrays
-are refused: this package has no CPU path.
+constant).  Pairwise functions are differentiable w.r.t. their FIRST argument.  CPU tensors are refused: this package
+has no CPU path.  numpy arrays -- the reference's functions carry a numpy branch each (detection/tools/IOU.py:60-66,130-146;
+metrics/map.py feeds it) -- are served by the SAME device kernels: uploaded, computed in fp32 on the GPU, returned as a numpy
+array of the input's dtype (INTEGRATION.md notes the one arithmetic difference: the reference's numpy branch of the pairwise
+xyxy / xywh IoU has no eps in the height factor, a 1e-7 relative effect).
 """
 import ctypes as C
 
@@ -47,11 +50,44 @@ class _PairFn(torch.autograd.Function):
         return ga, None, None, None, None, None
 
 
+def _from_numpy(a, b):
+    """(a, b as CUDA tensors, dtype to hand back) when the caller passed numpy arrays (or lists), else (a, b, None)."""
+    import numpy as np
+    if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+        return a, b, None
+    if not torch.cuda.is_available():
+        raise RuntimeError('fastvision_amd IoU: numpy inputs are computed on the GPU -- no device is available (there is no CPU path)')
+    na = a if isinstance(a, torch.Tensor) else np.asarray(a)
+    nb = b if isinstance(b, torch.Tensor) else np.asarray(b)
+    back = na.dtype if isinstance(na, np.ndarray) else nb.dtype
+    dev = next((t.device for t in (a, b) if isinstance(t, torch.Tensor) and t.is_cuda), torch.device('cuda', torch.cuda.current_device()))
+    up = lambda v: v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev)
+    return up(na), up(nb), (back if np.issubdtype(back, np.floating) else np.dtype(np.float32))
+
+
 def _pair(a, b, kind, mode, eps, variant=None):
-    return _PairFn.apply(a, b, kind, _MODE[mode], VARIANT if variant is None else variant, eps)
+    a, b, back = _from_numpy(a, b)
+    out = _PairFn.apply(a, b, kind, _MODE[mode], VARIANT if variant is None else variant, eps)
+    return out if back is None else _NumpyOut(out, back)
+
+
+class _NumpyOut:
+    """Result for numpy callers: converted on the first reshape (every public wrapper reshapes or returns it as is)."""
+
+    def __init__(self, t, dtype):
+        self.t, self.dtype = t, dtype
+
+    def reshape(self, *shape):
+        return self.t.detach().cpu().numpy().astype(self.dtype).reshape(*shape)
 
 
 def _batch(a, b, kind, mode, eps, variant=None):
+    a, b, back = _from_numpy(a, b)
+    out = _batch_dev(a, b, kind, mode, eps, variant)
+    return out if back is None else out.cpu().numpy().astype(back)
+
+
+def _batch_dev(a, b, kind, mode, eps, variant=None):
     fa, fb = _prep(a, 'iou_batch'), _prep(b, 'iou_batch')
     out = torch.empty((fa.shape[0], fb.shape[0]), dtype=torch.float32, device=fa.device)
     _lib.call('fva_iou_batch', kind, _MODE[mode], VARIANT if variant is None else variant, _p(fa), _p(fb), _p(out),
@@ -96,7 +132,7 @@ def cal_iou_batch(box1, box2, mode='xyxy', eps=1e-7):
 
 
 def GIOU(box1, box2, mode='xyxy', eps=1e-7):
-    return _pair(box1, box2, 1, mode, eps)                      # [N] (the reference returns a flat vector here)
+    return _pair(box1, box2, 1, mode, eps).reshape(-1)          # [N] (the reference returns a flat vector here)
 
 
 def GIOU_batch(box1, box2, mode='xyxy', eps=1e-7):

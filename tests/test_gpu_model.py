@@ -126,6 +126,16 @@ def test_iou_family_vs_reference(gold_lib, gold_demo):
         TT.cal_iou(a, b, mode='nope')
     with pytest.raises(RuntimeError):
         TT.xyxy_iou(a.cpu(), b.cpu())
+    # numpy callers (the reference's numpy branches, detection/tools/IOU.py:60-66,130-146): same kernels, numpy out in the input's dtype
+    an, bn = gold_lib['g2_a'].astype(np.float64), gold_lib['g2_b'].astype(np.float64)
+    got = TT.xyxy_iou(an, bn)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float64 and got.shape == gold_lib['g2_xyxy_iou'].shape
+    np.testing.assert_allclose(got, gold_lib['g2_xyxy_iou'], rtol=2e-5, atol=2e-6)
+    gb = TT.xyxy_iou_batch(an[:40].astype(np.float32), bn[:24].astype(np.float32))
+    assert isinstance(gb, np.ndarray) and gb.dtype == np.float32
+    np.testing.assert_allclose(gb, gold_lib['g2_xyxy_iou_batch'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(TT.wh_iou((an[:, 2:] - an[:, :2]), (bn[:, 2:] - bn[:, :2])), gold_lib['g2_wh_iou'], rtol=2e-5, atol=2e-6)
+    assert TT.GIOU(an, bn).shape == gold_lib['g2_giou'].shape
 
 
 # ------------------------------------------------------------------------------------------------ G3 losses + head grads
