@@ -1000,6 +1000,224 @@ int launch_pconv(const IgemmParams& p0, int B, int H, int W, bool flip, hipStrea
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Patch form of the STRIDE-2 data gradient of the thin 3x3 layers (64 -> 32 channels at 640^2, 128 -> 64 at 320^2; bf16).
+//   dx[2i + py][2j + px] = sum over the taps (kh, kw) with kh = 1 (py = 0) or kh in {0, 2} (py = 1), likewise kw / px, of
+//                          dy[i + (kh == 0)][j + (kw == 0)] . W[kh][kw]
+// Until round 3 these ran as two "paired" implicit-GEMM launches (both x parities as N' = 2 Cin columns: 4/3 of the MACs, every
+// tap's dy tile fetched again) -- 505 / 330 us for 1.26 / 1.05 GB of HBM traffic.  Here a block owns 4 x 32 cells = 8 x 64 dx
+// pixels: the (4+1) x (32+1) dy pixels they need are staged once (21 KiB per 64-channel slice), every tap is ONE shifted fragment
+// read feeding exactly the parity class it belongs to (the exact 9/4 MACs per dx pixel), wave w owns cell row w with eight
+// accumulator groups (4 parity classes x 2 halves of the row).  Weights: the plain [9][Cin][Cout] dgrad layout, resident (36 KiB)
+// or streamed through two slots like pconv_kernel; epilogue / statistics / store loop are the shared ones (512-row tile).
+template <int CS, int BN, int NSL, int EPI>
+__global__ __launch_bounds__(256, 2) void pdgrad2_kernel(const IgemmParams p) {
+    constexpr int CH = 4, CW = 32, PW = CW + 1, NPIX = (CH + 1) * PW;             // 165 dy pixels
+    constexpr int PIXB = CS * 2, CPP = PIXB / 16, PPI = 1024 / PIXB;
+    static_assert(CS == 64, "64-channel slices (128-byte pixel rows)");
+    constexpr int PATCH_INSTR = (NPIX + PPI - 1) / PPI, PATCH_BYTES = PATCH_INSTR * 1024;
+    constexpr int WSTEP_BYTES = BN * PIXB, WPW = WSTEP_BYTES / 1024 / 4;
+    static_assert(WSTEP_BYTES % 4096 == 0, "whole DMA instructions per wave");
+    constexpr int STEPS = 9 * NSL;
+    constexpr bool RESIDENT = NSL == 1 && 9 * WSTEP_BYTES <= 36 * 1024;
+    constexpr int WBUF_BYTES = (RESIDENT ? 9 : 2) * WSTEP_BYTES;
+    constexpr bool LOOPED = RESIDENT && EPI != EPI_BNB;   // the fused-statistics epilogue inside the tile loop spills (35 registers): one tile per block there
+    constexpr int BM = 512, NT = 256, NTILE = BN / 16, KS = CS / 32;
+    constexpr int PITCH = BN * 2 + 16, TILE_BYTES = BM * PITCH;
+    constexpr int WOFF = RESIDENT && TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
+    constexpr int COEF0 = TILE_BYTES > WOFF + WBUF_BYTES ? TILE_BYTES : WOFF + WBUF_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    char* const wbuf = smem + WOFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int tile0 = ((xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3)) * (LOOPED ? p.pt_tpb : 1);
+    const int Hp = p.in_img / p.in_row, Wp = p.in_row;
+    float* coef_tab = (float*)(smem + COEF0);
+    if constexpr (EPI == EPI_BNB) bnb_fill_lds<BN, NT>(p, coef_tab, tid, 0);
+    int b = 0, ty = 0, tx = 0, yorg = 0, xorg = 0;
+
+    auto swz = [](int r) { return (r >> 1) & 7; };
+    auto stage_patch = [&](int slice) {
+        const bf16_t* src0 = (const bf16_t*)p.in + (int64_t)b * p.in_img * p.C + slice * CS;
+#pragma unroll
+        for (int i = 0; i < (PATCH_INSTR + 3) / 4; ++i) {
+            const int j = i * 4 + w;
+            if (j < PATCH_INSTR) {
+                int pix = j * PPI + lane / CPP;
+                pix = pix < NPIX ? pix : NPIX - 1;
+                const int py = (pix * 1986) >> 16, px = pix - py * PW;             // / 33, exact below 400
+                int iy = yorg + py, ix = xorg + px;
+                iy = iy < Hp ? iy : Hp - 1;
+                ix = ix < Wp ? ix : Wp - 1;
+                const int chunk = (lane % CPP) ^ swz(j * PPI + lane / CPP);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + ((int64_t)iy * Wp + ix) * p.C + chunk * 8), LDS_PTR(patch + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int step, char* dst) {                          // step = slice * 9 + tap (tap = kh * 3 + kw)
+        const int slice = step / 9, tap = step - slice * 9;
+        const bf16_t* src0 = (const bf16_t*)p.wt + (int64_t)tap * p.N * p.C + slice * CS;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int j = i * 4 + w;
+            const int n = j * PPI + lane / CPP;
+            const int nn = n < p.N ? n : p.N - 1;
+            const int chunk = (lane % CPP) ^ swz(n);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + (int64_t)nn * p.C + chunk * 8), LDS_PTR(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][2][NTILE];            // [parity class py * 2 + px][half of the cell row][n tile]
+    int pix0[2];
+    int opq = 0;
+    auto compute = [&](int tap, const char* wb) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int cls = (kh == 1 ? 0 : 2) + (kw == 1 ? 0 : 1);
+        const int tapoff = (kh == 0 ? PW : 0) + (kw == 0 ? 1 : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[2], bfr[NTILE];
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt) {
+                const int pix = pix0[xt] + tapoff;
+                af[xt] = *(const bf16x8*)(patch + pix * PIXB + (((ks * 4 + g) ^ swz(pix)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt) {
+                const int n = nt * 16 + r16 + opq;
+                bfr[nt] = *(const bf16x8*)(wb + n * PIXB + (((ks * 4 + g) ^ swz(n)) << 4));
+            }
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+                for (int nt = 0; nt < NTILE; ++nt) acc[cls][xt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[xt], bfr[nt], acc[cls][xt][nt], 0, 0, 0);
+        }
+    };
+
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) stage_w(t, wbuf + t * WSTEP_BYTES);
+    }
+#pragma unroll 1
+    for (int it = 0; it < (LOOPED ? p.pt_tpb : 1); ++it) {
+    const int tile = tile0 + it;
+    if (tile >= p.pt_tiles) break;
+    b = (int)fd_div((uint32_t)tile, p.pt_div_img);
+    {
+        const int trem = tile - b * (p.pt_tx * p.pt_ty);
+        ty = (int)fd_div((uint32_t)trem, p.pt_div_tx);
+        tx = trem - ty * p.pt_tx;
+    }
+    yorg = p.y0 + ty * CH;                                             // first dy pixel of the patch in the padded dy buffer
+    xorg = p.x0 + tx * CW;
+    asm volatile("" : "+v"(opq));
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) pix0[xt] = w * PW + xt * 16 + r16 + opq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTILE; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RESIDENT) {
+        stage_patch(0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) compute(t, wbuf + t * WSTEP_BYTES);
+    } else {
+        stage_patch(0);
+        stage_w(0, wbuf);
+#pragma unroll 1
+        for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int s = sl * 9 + t;
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (NSL > 1 && t == 0 && sl > 0) {
+                    stage_patch(sl);
+                    stage_w(s + 1, wbuf + ((s + 1) & 1) * WSTEP_BYTES);
+                    wait_vmcnt<WPW>();
+                    __builtin_amdgcn_s_barrier();
+                } else if (s + 1 < STEPS) {
+                    stage_w(s + 1, wbuf + ((s + 1) & 1) * WSTEP_BYTES);
+                }
+                compute(t, wbuf + (s & 1) * WSTEP_BYTES);
+            }
+        }
+    }
+    __syncthreads();   // LDS is free for the epilogue
+    // accumulator element (class (py, px), half xt, j) = dx pixel (2 w + py, 2 (16 xt + 4 g + j) + px) of the 8 x 64 tile
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(bf16_t*)(smem + ((2 * w + (c >> 1)) * 64 + 2 * (xt * 16 + g * 4 + j) + (c & 1)) * PITCH + (nt * 16 + r16) * 2) = (bf16_t)acc[c][xt][nt][j];
+    __syncthreads();
+    store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, 0, tile, [&](int rr) -> int64_t {
+        const int oy = ty * 2 * CH + (rr >> 6), ox = tx * 2 * CW + (rr & 63);
+        return oy < p.pt_H && ox < p.pt_W ? ((int64_t)b * p.pt_H + oy) * p.pt_W + ox : (int64_t)-1;
+    }, nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
+    __syncthreads();
+    }
+}
+
+// stride-2 3x3 bf16 data gradients served by pdgrad2_kernel: reduction over C = Cout channels, N = Cin outputs.  Decided by the
+// channel counts alone (the weight packer must know the layout without seeing a feature-map size: these layers take the plain
+// [9][Cin][Cout] dgrad weights, the other thin stride-2 layers the paired layout).  FVA_PDGRAD2=0 switches it off.
+inline bool use_pdgrad2(int dtype, int ksize, int stride, int C, int N) {
+    static const bool on = [] { const char* e = getenv("FVA_PDGRAD2"); return !e || atoi(e) != 0; }();
+    return on && dtype == FVA_BF16 && ksize == 3 && stride == 2 && ((C == 64 && N == 32) || (C == 128 && N == 64));
+}
+inline int pdgrad2_tiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 64); }   // H, W: the dx image
+
+template <int CS, int BN, int NSL, int EPI>
+int launch_pdgrad2_one(const IgemmParams& p0, int tiles, hipStream_t s) {
+    constexpr int PIXB = CS * 2, PPI = 1024 / PIXB, PATCH_BYTES = ((165 + PPI - 1) / PPI) * 1024, WSTEP = BN * PIXB;
+    constexpr bool RESIDENT = NSL == 1 && 9 * WSTEP <= 36 * 1024;
+    constexpr int WBUF = (RESIDENT ? 9 : 2) * WSTEP, TILE = 512 * (BN * 2 + 16);
+    constexpr int WOFF = RESIDENT && TILE > PATCH_BYTES ? TILE : PATCH_BYTES;
+    constexpr int smem = (TILE > WOFF + WBUF ? TILE : WOFF + WBUF) + (EPI == EPI_BNB ? 4 * BN * 4 : 0);
+    static_assert(smem <= 80 * 1024, "two blocks per CU");
+    static const int tpb_env = [] { const char* e = getenv("FVA_PCONV_TPB"); return e ? atoi(e) : 0; }();
+    IgemmParams p = p0;
+    p.pt_tiles = tiles;
+    p.pt_tpb = RESIDENT && EPI != EPI_BNB ? (tpb_env > 0 ? tpb_env : 2) : 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)pdgrad2_kernel<CS, BN, NSL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pdgrad2_kernel<CS, BN, NSL, EPI>), dim3(cdiv(tiles, p.pt_tpb)), dim3(256), smem, s, p);
+    FVA_LAUNCH_CHECK("pdgrad2_kernel");
+    return FVA_OK;
+}
+
+// p: in = dy halo buffer (in_row / in_img / y0 = x0 = dy_pad), wt = [9][Cin][Cout], out = dx dense, N = Cin, C = Cout; H, W = dx image
+template <int EPI>
+int launch_pdgrad2(const IgemmParams& p0, int B, int H, int W, hipStream_t s) {
+    IgemmParams p = p0;
+    p.pt_H = H;
+    p.pt_W = W;
+    p.pt_tx = cdiv(W, 64);
+    p.pt_ty = cdiv(H, 8);
+    p.pt_div_tx = make_fastdiv(p.pt_tx);
+    p.pt_div_img = make_fastdiv(p.pt_tx * p.pt_ty);
+    const int tiles = pdgrad2_tiles(B, H, W);
+    if (p.C == 64 && p.N == 32) return launch_pdgrad2_one<64, 32, 1, EPI>(p, tiles, s);
+    if (p.C == 128 && p.N == 64) return launch_pdgrad2_one<64, 64, 2, EPI>(p, tiles, s);
+    return fva_fail(FVA_ERR_ARG, "pdgrad2: unsupported channels %d -> %d", p.C, p.N);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 along m x 4 along n, 128x64 each), the "8-phase" schedule of the CDNA GEMM playbook
 // (cdna_hip_programming.md section 5): one block per CU, two LDS buffers of four 16-KiB half-tiles (A rows / B rows of the
 // first and second half of every wave's sub-tile), a k-tile consumed in four phases of 16 MFMAs (one 64x32 quadrant of
@@ -1630,10 +1848,12 @@ inline int pair_max_cin() {
     }();
     return v;
 }
-inline bool dgrad_paired(int ksize, int stride, int Cin) { return ksize == 3 && stride == 2 && Cin <= pair_max_cin(); }
+inline bool dgrad_paired(int dtype, int ksize, int stride, int Cin, int Cout) {
+    return ksize == 3 && stride == 2 && Cin <= pair_max_cin() && !use_pdgrad2(dtype, ksize, stride, Cout, Cin);
+}
 
 int packed_taps(const fva_conv_desc* d, int for_dgrad) {
-    if (for_dgrad && dgrad_paired(d->ksize, d->stride, d->Cin)) return 12;   // 6 virtual taps x 2 parities
+    if (for_dgrad && dgrad_paired(d->dtype, d->ksize, d->stride, d->Cin, d->Cout)) return 12;   // 6 virtual taps x 2 parities
 
     const int kk = d->ksize * d->ksize;
     const int C = for_dgrad ? d->Cout : d->Cin;
@@ -1704,7 +1924,7 @@ int fva_conv_pack_weights(const fva_conv_desc* d, const float* w, void* w_fwd, v
     int rc = check_desc(d, "fva_conv_pack_weights");
     if (rc) return rc;
     if (!w) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights: null weights");
-    const int paired = dgrad_paired(d->ksize, d->stride, d->Cin) ? 1 : 0;
+    const int paired = dgrad_paired(d->dtype, d->ksize, d->stride, d->Cin, d->Cout) ? 1 : 0;
     const int tf = packed_taps(d, 0), td = paired ? d->ksize * d->ksize : packed_taps(d, 1);
     const int64_t total = (int64_t)(tf > td ? tf : td) * d->Cout * d->Cin;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -1904,7 +2124,8 @@ int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d) {
     if (use_pconv(d->dtype, k, s, d->Cout, d->Cin, d->H, d->W)) return pconv_tiles(d->B, d->H, d->W);
     if (s == 1) return dgrad_launch_rows(d, (int64_t)d->B * d->H * d->W, d->Cin, d->Cout, k * k, in_pixels);
     const int64_t mq = (int64_t)d->B * (d->H / 2) * (d->W / 2);
-    if (dgrad_paired(k, s, d->Cin)) {   // two launches (row parity) of N' = 2 * Cin columns: two table rows per block
+    if (use_pdgrad2(d->dtype, k, s, d->Cout, d->Cin)) return pdgrad2_tiles(d->B, d->H, d->W);
+    if (dgrad_paired(d->dtype, k, s, d->Cin, d->Cout)) {   // two launches (row parity) of N' = 2 * Cin columns: two table rows per block
         int rows = 0;
         for (int py = 0; py < 2; ++py) rows += 2 * dgrad_launch_rows(d, mq, 2 * d->Cin, d->Cout, py == 0 ? 2 : 4, in_pixels);
         return rows;
@@ -1988,7 +2209,12 @@ int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgra
         return f ? launch_igemm<EPI_BNB>(d->dtype, p, (hipStream_t)stream) : launch_igemm<EPI_PLAIN>(d->dtype, p, (hipStream_t)stream);
     }
     const int JH = d->H / 2, JW = d->W / 2;
-    if (dgrad_paired(k, s, d->Cin)) {
+    if (use_pdgrad2(d->dtype, k, s, d->Cout, d->Cin)) {
+        p.y0 = p.x0 = d->dy_pad;          // dy pixel (i, j) sits at padded (i + pad, j + pad); rows / columns up to OH / OW are the zero halo
+        p.out_dense = 1;
+        return f ? launch_pdgrad2<EPI_BNB>(p, d->B, d->H, d->W, (hipStream_t)stream) : launch_pdgrad2<EPI_PLAIN>(p, d->B, d->H, d->W, (hipStream_t)stream);
+    }
+    if (dgrad_paired(d->dtype, k, s, d->Cin, d->Cout)) {
         // thin layers: both x-parities of an output row per launch (see dgrad_paired) -- 2 launches, N' = 2*Cin
         p.M = d->B * JH * JW;
         p.N = 2 * d->Cin;

@@ -82,6 +82,16 @@ class GraphedTrainStep:
         # warm-up steps do the lazy one-time work (kernel attributes, pointer tables, allocator growth, Adam state) -- on a copy of
         # the training state that is put back afterwards, so that capture leaves parameters, statistics and moments untouched
         from . import ops
+        if side_stream:
+            # Diagnosed in round 3 (tools/hwq_capture_check.py under faulthandler): with GPU_MAX_HW_QUEUES=2 a graph that holds a second
+            # branch captures, then segfaults on the HOST inside hipGraphLaunch (torch/cuda/graphs.py replay) -- the runtime maps
+            # parallel branches onto hardware queues it was told not to create; 4 queues replay fine, and so does the single-stream
+            # capture with 2.  Refuse the combination instead of crashing the process.
+            import os
+            q = os.environ.get('GPU_MAX_HW_QUEUES')
+            if q is not None and q.strip().isdigit() and int(q) < 4:
+                raise RuntimeError(f'GraphedTrainStep(side_stream=True): a two-branch HIP graph crashes in hipGraphLaunch with GPU_MAX_HW_QUEUES={q} '
+                                   '(< 4) on ROCm 7.2; capture single-stream (the default) or allow at least 4 hardware queues')
         side_was = ops.set_wgrad_side_stream(bool(side_stream) and ops._SIDE['on'])
         try:
             snap = self._snapshot()

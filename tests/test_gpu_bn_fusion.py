@@ -24,7 +24,7 @@ CASES = [
     (2, 64, 128, 16, 16, 3, 1),      # thin 256x64 tile
     (1, 256, 128, 13, 13, 1, 1),     # 1x1, two column blocks
     (3, 128, 128, 8, 12, 3, 2),      # stride 2: four parity launches
-    (2, 64, 128, 16, 16, 3, 2),      # stride 2, thin: two paired launches (N' = 2 * Cin)
+    (2, 64, 128, 16, 16, 3, 2),      # stride 2, thin: the stride-2 patch kernel in bf16 (two paired launches, N' = 2 * Cin, in fp32)
     (8, 256, 512, 64, 64, 3, 1),     # 8-phase 256x256 kernel (bf16): 128 tiles, 72 k-tiles
 ]
 

@@ -110,7 +110,7 @@ BWD_CASES = [
     (4, 256, 128, 40, 40, 1, 1),     # 1x1, two column blocks, 50 row blocks... and
     (8, 128, 256, 40, 40, 1, 1),     # 100 row blocks: two levels
     (3, 128, 128, 8, 12, 3, 2),      # stride 2: four parity launches share the table and the counters
-    (2, 64, 128, 16, 16, 3, 2),      # stride 2, thin: two paired launches (N' = 2 * Cin: two table rows per block)
+    (2, 64, 128, 16, 16, 3, 2),      # stride 2, thin: bf16 the stride-2 patch kernel; fp32 two paired launches (N' = 2 * Cin: two table rows per block)
     (2, 32, 64, 32, 32, 3, 2),       # the same with Cin = 32: a slice is one pixel parity
     (8, 256, 512, 64, 64, 3, 1),     # 8-phase 256x256 kernel (bf16)
     (2, 64, 128, 72, 64, 3, 1),      # patch kernel (bf16): reduction over 128 channels in two slices, N = 64

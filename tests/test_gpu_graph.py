@@ -153,6 +153,19 @@ def test_graphed_step_refuses_what_it_cannot_capture():
     step = GraphedTrainStep(net, crit, opt, im.to(DEV), tg.to(DEV), max_targets=tg.shape[0])
     with pytest.raises(ValueError):
         step(im.to(DEV), torch.cat([tg, tg]).to(DEV))                                                 # more targets than captured
+    # a two-branch graph with fewer than four hardware queues segfaults in hipGraphLaunch (diagnosed: tools/hwq_capture_check.py):
+    # refused before anything is captured
+    import os
+    old = os.environ.get('GPU_MAX_HW_QUEUES')
+    os.environ['GPU_MAX_HW_QUEUES'] = '2'
+    try:
+        with pytest.raises(RuntimeError, match='GPU_MAX_HW_QUEUES'):
+            GraphedTrainStep(net, crit, opt, im.to(DEV), tg.to(DEV), side_stream=True)
+    finally:
+        if old is None:
+            del os.environ['GPU_MAX_HW_QUEUES']
+        else:
+            os.environ['GPU_MAX_HW_QUEUES'] = old
 
 
 def test_graphed_demo_step_is_bit_identical_with_eager():

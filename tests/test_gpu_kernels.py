@@ -52,6 +52,9 @@ CONV_CASES = [
     (1, 64, 128, 70, 72, 3, 1),      # forward C = 64 / N = 128 (weight ring), dgrad C = 128 / N = 64 (two channel slices); patches overhang both ways
     (1, 128, 64, 66, 64, 3, 1),      # forward two channel slices, dgrad the weight ring
     (1, 64, 64, 64, 65, 3, 1),       # C = N = 64
+    # thin 3x3 stride-2 layers: the data gradient runs on the stride-2 patch kernel (bf16; the small stride-2 cases above too)
+    (1, 32, 64, 72, 136, 3, 2),      # dgrad C = 64 / N = 32, resident weights; 8 x 64 dx tiles overhang in x
+    (1, 64, 128, 40, 72, 3, 2),      # dgrad C = 128 in two slices / N = 64, weight ring; overhang both ways
 ]
 
 
