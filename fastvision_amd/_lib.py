@@ -25,7 +25,7 @@ class HeadLevel(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [('w', C.c_void_p), ('w_fwd', C.c_void_p), ('w_dgrad', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype', 'dgrad_paired', 'reserved')]
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'ksize', 'taps_fwd', 'taps_dgrad', 'dtype', 'dgrad_paired', 'tile_start')]
 
 
 class Letterbox(C.Structure):
@@ -83,6 +83,7 @@ PROTOTYPES = {
     'fva_conv_pack_weights': (_I, [_D, _P, _P, _P, _P]),
     'fva_conv_packed_elems': (_L, [_D, _I]),
     'fva_conv_pack_weights_multi': (_I, [_P, _I, _L, _P]),
+    'fva_conv_pack_weights_tiled': (_I, [_P, _I, _I, _P]),
     'fva_conv_workspace_bytes': (_L, []),
     'fva_conv_set_workspace': (_I, [_P, _L]),
     'fva_conv_streamk_timeouts': (_L, []),

@@ -448,7 +448,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     // finished reading (counted vmcnt: LDS-DMA retires in issue order).
     static_assert(NSTAGE == 2, "the loop below is written for two stages");
     constexpr int LPT = A_ITERS + B_ITERS;  // DMA instructions per wave and tile
-    if constexpr (COEF_BYTES > 0) {
+#ifndef FVA_COEF_LATE
+#define FVA_COEF_LATE 1
+#endif
+    if constexpr (COEF_BYTES > 0 && !FVA_COEF_LATE) {
         // before the first LDS-DMA (hipcc drains vmcnt in front of an LDS access once one is in flight); the values were requested
         // ahead of the epilogue operands, so the wait covers loads that have long returned.  Read in the epilogue, behind the barriers.
 #pragma unroll
@@ -512,6 +515,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     }
     __syncthreads();  // LDS is free for the epilogue
     stamp(3);
+    if constexpr (COEF_BYTES > 0 && FVA_COEF_LATE) {
+        // round 3: the table is written HERE, behind the k loop -- its values were requested at block entry and returned long ago, no
+        // LDS-DMA is in flight, and the first DMA of the block no longer waits for them (the write used to sit in front of it: a
+        // global round trip of the 4-5 us "setup" phase of every fused 1x1 dgrad tile, profiles/r02_tile_phases.md).  Read in the
+        // store loop, behind the barrier that follows the transposition.
+#pragma unroll
+        for (int j = 0; j < COEF_PER_THREAD; ++j) coef_tab[tid + j * NT] = coef_v[j];
+    }
 
     const int wrow0 = wr * 64, wcol0 = wc * 64;
 
@@ -1838,6 +1849,104 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const fva_pack_
     }
 }
 
+// The same re-pack with ONE block per 32 (Cout) x 32 (Cin) tile of ANY layer (round 3): the 2-D grid above starts 512 blocks per
+// layer whatever its size (38 400 blocks for YOLOv3's 75 layers, most of which find nothing to do), its tile load divides every
+// index by 32 k^2 and its stores are 2 bytes per lane -- 287 us per step for 0.5 GB (1.7 TB/s).  Here the caller numbers the tiles
+// of all layers consecutively (entry.tile_start = tiles of the entries before it), a block finds its layer by bisection, aligned
+// tiles (k = 3 or 1, whole 32 x 32) load 16 bytes per lane and store four bf16 per lane (whole 64-byte rows); ragged or fp32
+// tiles and the paired layout take the element-wise path of the kernel above.
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const fva_pack_entry* __restrict__ table, int n) {
+    __shared__ float tile[32][32 * 9 + 1];
+    int lo = 0, hi = n - 1;                       // last entry whose tile_start <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const fva_pack_entry e = table[lo];
+    const int kk = e.ksize * e.ksize;
+    const int tci = (e.Cin + 31) / 32;
+    const int tl = (int)blockIdx.x - e.tile_start;
+    const int co0 = (tl / tci) * 32, ci0 = (tl % tci) * 32;
+    const bool bf = e.dtype == FVA_BF16;
+    const int tid = threadIdx.x;
+    const bool whole = co0 + 32 <= e.Cout && ci0 + 32 <= e.Cin;
+    if (whole && bf && (kk == 9 || kk == 1) && !e.dgrad_paired && e.Cin % 4 == 0 && e.Cout % 4 == 0 && ((uintptr_t)e.w & 15) == 0) {   // 16-byte loads, 8-byte stores
+        const int rowf4 = 8 * kk;                 // float4 per tile row (32 ci x kk floats, 16-byte aligned: ci0 * kk * 4 bytes)
+        for (int i = tid; i < 32 * rowf4; i += 256) {
+            const int r = i / rowf4, c4 = i - r * rowf4;
+            const f32x4 v = *(const f32x4*)(e.w + ((int64_t)(co0 + r) * e.Cin + ci0) * kk + c4 * 4);
+            tile[r][c4 * 4 + 0] = v[0]; tile[r][c4 * 4 + 1] = v[1]; tile[r][c4 * 4 + 2] = v[2]; tile[r][c4 * 4 + 3] = v[3];
+        }
+        __syncthreads();
+        const int row = tid >> 3, q = (tid & 7) * 4;   // 32 rows x 8 lanes x 4 elements
+        for (int t = 0; t < kk; ++t) {
+            if (e.w_fwd) {                             // [t][co][ci]: row = co, four consecutive ci
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)tile[row][(q + j) * kk + t];
+                *(bf16x4*)((bf16_t*)e.w_fwd + ((int64_t)t * e.Cout + co0 + row) * e.Cin + ci0 + q) = o;
+            }
+            if (e.w_dgrad) {                           // [t][ci][co]: row = ci, four consecutive co
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)tile[q + j][row * kk + t];
+                *(bf16x4*)((bf16_t*)e.w_dgrad + ((int64_t)t * e.Cin + ci0 + row) * e.Cout + co0 + q) = o;
+            }
+        }
+    } else {
+        const int ncol = (e.Cin - ci0 < 32 ? e.Cin - ci0 : 32) * kk;
+        for (int i = tid; i < 32 * 32 * kk; i += 256) {
+            const int r = i / (32 * kk), c = i - r * (32 * kk);
+            tile[r][c] = (co0 + r < e.Cout && c < ncol) ? e.w[((int64_t)(co0 + r) * e.Cin + ci0) * kk + c] : 0.f;
+        }
+        __syncthreads();
+        const int a = tid >> 5, l = tid & 31;
+        for (int t = 0; t < kk; ++t) {
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += 8) {
+                const int r = rr + a;
+                if (e.w_fwd && co0 + r < e.Cout && ci0 + l < e.Cin) {
+                    const int64_t o = ((int64_t)t * e.Cout + co0 + r) * e.Cin + ci0 + l;
+                    const float v = tile[r][l * kk + t];
+                    if (bf) ((bf16_t*)e.w_fwd)[o] = (bf16_t)v; else ((float*)e.w_fwd)[o] = v;
+                }
+                if (e.w_dgrad && ci0 + r < e.Cin && co0 + l < e.Cout) {
+                    const float v = tile[l][r * kk + t];
+                    if (e.dgrad_paired) {
+                        const int64_t row = paired_row(t, ci0 + r, e.Cin);
+                        const int64_t o = row * e.Cout + co0 + l;
+                        if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                        if (t % 3 == 0) {
+                            const int64_t z = (row - e.Cin) * e.Cout + co0 + l;
+                            if (bf) ((bf16_t*)e.w_dgrad)[z] = (bf16_t)0.f; else ((float*)e.w_dgrad)[z] = 0.f;
+                        }
+                    } else {
+                        const int64_t o = ((int64_t)t * e.Cin + ci0 + r) * e.Cout + co0 + l;
+                        if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)v; else ((float*)e.w_dgrad)[o] = v;
+                    }
+                }
+            }
+        }
+    }
+    // zero pad tap (bf16 half-row k-tiles): taps_* may exceed k*k by one -- this tile's share of it
+    if (e.taps_fwd > kk || (!e.dgrad_paired && e.taps_dgrad > kk)) {
+        const int64_t cc = (int64_t)e.Cout * e.Cin;
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            if (co0 + r < e.Cout && ci0 + c < e.Cin) {
+                if (e.w_fwd && e.taps_fwd > kk) {
+                    const int64_t o = kk * cc + (int64_t)(co0 + r) * e.Cin + ci0 + c;
+                    if (bf) ((bf16_t*)e.w_fwd)[o] = (bf16_t)0.f; else ((float*)e.w_fwd)[o] = 0.f;
+                }
+                if (e.w_dgrad && !e.dgrad_paired && e.taps_dgrad > kk) {
+                    const int64_t o = kk * cc + (int64_t)(ci0 + c) * e.Cout + co0 + r;
+                    if (bf) ((bf16_t*)e.w_dgrad)[o] = (bf16_t)0.f; else ((float*)e.w_dgrad)[o] = 0.f;
+                }
+            }
+        }
+    }
+}
+
 // Stride-2 dgrad of thin layers: the two output x-parities of a row are produced together as N' = 2*Cin columns (the
 // pixel pair (2j, 2j+1) is contiguous in NHWC), from "virtual taps" v = ky*2 + dxo whose [2*Cin][Cout] matrices hold
 // kx=1 | kx=2 for dxo=0 and zeros | kx=0 for dxo=1.  2 launches instead of 4, full-line stores, 4/3 of the MACs.
@@ -1941,6 +2050,13 @@ int fva_conv_pack_weights_multi(const fva_pack_entry* table_dev, int32_t n, int6
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, table_dev);
     FVA_LAUNCH_CHECK("pack_weights_multi_kernel");
+    return FVA_OK;
+}
+
+int fva_conv_pack_weights_tiled(const fva_pack_entry* table_dev, int32_t n, int32_t total_tiles, void* stream) {
+    if (!table_dev || n < 1 || total_tiles < 1) return fva_fail(FVA_ERR_ARG, "fva_conv_pack_weights_tiled: bad argument");
+    hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+    FVA_LAUNCH_CHECK("pack_weights_tiled_kernel");
     return FVA_OK;
 }
 

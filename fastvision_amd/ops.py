@@ -186,20 +186,25 @@ class _PackRegistry:
             return
         if self.table is None or self.table[0] != len(live) or self.table[3] != device:
             arr = (_lib.PackEntry * len(live))()
-            mx = 0
+            mx = tiles = 0
             for i, (w, (co, ci, k, dt, st), wf, wd) in enumerate(live):
                 e = arr[i]
                 e.w, e.w_fwd, e.w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
                 e.Cout, e.Cin, e.ksize, e.dtype = co, ci, k, dt
                 e.taps_fwd, e.taps_dgrad = wf.numel() // (co * ci), wd.numel() // (co * ci)
                 e.dgrad_paired = 1 if (st == 2 and e.taps_dgrad == 12) else 0
+                e.tile_start = tiles                         # one block per 32 x 32 weight tile (fva_conv_pack_weights_tiled)
+                tiles += ((co + 31) // 32) * ((ci + 31) // 32)
                 mx = max(mx, wf.numel(), wd.numel())
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-            self.table = (len(live), raw, mx, device, [w.data_ptr() for w, *_ in live])
+            self.table = (len(live), raw, mx, device, [w.data_ptr() for w, *_ in live], tiles)
         if self.table[4] != [w.data_ptr() for w, *_ in live]:      # a parameter moved: rebuild
             self.table = None
             return self.repack_all(device)
-        _lib.call('fva_conv_pack_weights_multi', _p(self.table[1]), self.table[0], self.table[2], _stream())
+        if os.environ.get('FVA_PACK_TILED', '1') != '0':
+            _lib.call('fva_conv_pack_weights_tiled', _p(self.table[1]), self.table[0], self.table[5], _stream())
+        else:
+            _lib.call('fva_conv_pack_weights_multi', _p(self.table[1]), self.table[0], self.table[2], _stream())
         for w, (co, ci, k, dt, st), wf, wd in live:
             w._fva_packed = ((w._version, w.data_ptr(), dt), wf, wd)
 

@@ -91,9 +91,13 @@ typedef struct {
     int32_t Cout, Cin, ksize, taps_fwd, taps_dgrad, dtype;
     int32_t dgrad_paired; /* 1 when taps_dgrad == 12: the paired stride-2 layout [6][2*Cin][Cout] thin layers use
                            * (fva_conv_packed_elems() of a stride-2 descriptor tells; see conv_igemm.hip dgrad_paired) */
-    int32_t reserved;
+    int32_t tile_start;   /* fva_conv_pack_weights_tiled: 32 x 32 (Cout x Cin) tiles of the entries BEFORE this one, i.e. the running sum of
+                           * ceil(Cout / 32) * ceil(Cin / 32); ignored by fva_conv_pack_weights_multi */
 } fva_pack_entry;
 int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t max_elems, void* stream);
+/* The same result from a launch of ONE block per 32 x 32 weight tile of any layer (total_tiles = the running sum after the last
+ * entry): no idle blocks for small layers, 16-byte loads and 8-byte stores on aligned bf16 tiles. */
+int fva_conv_pack_weights_tiled(const fva_pack_entry* table, int32_t n, int32_t total_tiles, void* stream);
 
 /* Optional scratch for the EXPERIMENTAL stream-K form of the 256x256 MFMA kernel (env FVA_STREAMK=1; measured slower than
  * whole tiles at B = 32, off by default): one 256-KiB accumulator slab per CU + flags.  The caller owns the buffer, zero-fills it once,

@@ -244,7 +244,7 @@ def test_multi_tensor_weight_pack_matches_single(key):
     from fastvision_amd import _lib, ops
     dtype = DT[key]
     lib = _lib.load()
-    shapes = [(64, 32, 3), (32, 64, 1), (255, 128, 1), (128, 64, 3), (48, 40, 3)]
+    shapes = [(64, 32, 3), (32, 64, 1), (255, 128, 1), (128, 64, 3), (48, 40, 3), (256, 128, 3), (64, 128, 3)]
     g = torch.Generator().manual_seed(9)
     ws = [torch.randn(co, ci, k, k, generator=g).to(dev()) for co, ci, k in shapes]
     arr = (_lib.PackEntry * len(ws))()
@@ -262,6 +262,17 @@ def test_multi_tensor_weight_pack_matches_single(key):
         mx = max(mx, wf.numel(), wd.numel())
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
     _lib.call('fva_conv_pack_weights_multi', ops._p(table), len(ws), mx, ops._stream())
+    for (sf, sd), (mf, md) in zip(singles, multis):
+        assert torch.equal(sf.float(), mf.float()) and torch.equal(sd.float(), md.float())
+    # ... and the tiled launch (one block per 32 x 32 weight tile of any layer: what the pack registry uses)
+    for mf, md in multis:
+        mf.fill_(float('nan')); md.fill_(float('nan'))
+    tiles = 0
+    for i, (co, ci, k) in enumerate(shapes):
+        arr[i].tile_start = tiles
+        tiles += ((co + 31) // 32) * ((ci + 31) // 32)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    _lib.call('fva_conv_pack_weights_tiled', ops._p(table), len(ws), tiles, ops._stream())
     for (sf, sd), (mf, md) in zip(singles, multis):
         assert torch.equal(sf.float(), mf.float()) and torch.equal(sd.float(), md.float())
 
