@@ -621,11 +621,14 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
     if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
+    // EXPERIMENT (FVA_APPLY_LDS=bytes): an unused dynamic LDS allocation caps the blocks per CU (160 KiB / bytes), so that a
+    // weight-gradient block of the low-priority side stream (64 KiB, one wave per SIMD) finds LDS and registers beside this pass
+    static const int cap_lds = [] { const char* e = getenv("FVA_APPLY_LDS"); return e ? atoi(e) : 0; }();
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), cap_lds, s, (const bf16_t*)dz, (const bf16_t*)y,
                            scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(B * h.Hp), dim3(256), 0, s, (const float*)dz, (const float*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(B * h.Hp), dim3(256), cap_lds, s, (const float*)dz, (const float*)y,
                            scale, shift, save_mean, save_rstd, coef, (float*)dy, h);
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return FVA_OK;

@@ -524,6 +524,225 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     stamp(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// All-taps weight gradient of the thin 3x3 layers (32 -> 64 and 64 -> 128 channels, stride 1 and 2, bf16; round 3).
+// wgrad_kernel gives these layers a 128 x 128 tile per tap group: with Cin = 32 four taps share a column tile (three groups for nine
+// taps, the last a quarter full), every group re-reads the dY tile, and each tap's X rows are fetched separately -- 360-380 us for
+// 0.12 TFLOP.  Here a block of four waves owns a [64][9 Cin] slice of the gradient in its accumulators (all of it for Cout = 64, one
+// of two halves for 128) and walks a run of output patches (TH x 32 pixels): per patch the dY tile and the input pixels under it are
+// staged once (pixel-major rows, LDS-DMA), and a 32-pixel k-step of patch row r takes its A fragments (dY^T) and, for every tap, its B
+// fragments (X at the tap's pixel offset) by transposing LDS reads (ds_read_b64_tr_b16) from those two images.  No dead MFMAs, one
+// staging of X for nine taps, one of dY for all of them.
+//  * Every fragment address is  (a per-lane register set up once per kernel) + (an immediate that depends on r only): the swizzle of
+//    the 32-byte column blocks is a function of the pixel's COLUMN in the patch (never of its row), so a row step is a constant byte
+//    offset.  The first version recomputed tap, block and swizzle per read: ~300 VALU instructions per k-step against 18 MFMAs, and
+//    ran slower than the tap groups (profiles/r03_experiments.md).
+//  * Stride 2: the patch's input columns are stored de-interleaved (even columns, then odd ones), so that the 32 input pixels of a
+//    k-step of one tap are consecutive LDS rows as for stride 1, and the same conflict-free swizzle holds.
+//  * Bank argument (64 banks x 4 B; a b64 read is served half a wave at a time): lanes 0-31 read 8 pixel rows x 32 bytes, rows
+//    o + {0..3, 8..11}.  Row pitch 64 B (Cin = 32): four consecutive rows fill a 256-byte window once, rows + 8 fall on the same
+//    slots and take the other 32-byte half -- swizzle bit = bit 3 of the column.  Pitch 128 B (Cin = 64, and dY's 64 channels): rows
+//    {o, o+2, o+8, o+10} share a slot of four blocks -- swizzle = (bit 1, bit 3) of the column, distinct for the four (checked
+//    exhaustively for every offset, tools/check_pwgrad_banks.py).
+// Split-K = the blocks' runs of patches; slab [run][tap][Cout][Cin] fp32 and the fixed-order reduce are wgrad_kernel's.
+struct PwgradParams {
+    const void* x;
+    const void* dy;
+    float* slab;
+    int B, OH, OW;                 // output (dY) image
+    int x_img, x_row, x_y0, x_x0;  // padded input: pixels per image / row, padded coordinates of input pixel (-1, -1) relative to output (0, 0)
+    int dy_img, dy_row, dy_pad;
+    int tx, ty, tiles, per_block;  // patches per image (x, y), total, per run
+    int runs;
+    FastDiv div_tx, div_img;
+};
+
+#ifndef FVA_PWGRAD_ABL
+#define FVA_PWGRAD_ABL 0      // timing experiments (results wrong): 1 = staging only, 2 = only the first patch of a run is staged,
+                              // 3 = as 2 without the fragment reads (MFMAs only), 4 = as 2 without the MFMAs (fragment reads only)
+#endif
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int C, int NTOT, int STRIDE, int TH>
+__global__ __launch_bounds__(256, (C == 32 && TH * STRIDE <= 4) ? 3 : 2) void pwgrad_kernel(const PwgradParams p) {
+    constexpr int TW = 32, NB = 64, NH = NTOT / NB;
+    constexpr int XW = STRIDE * TW + 2, XH = STRIDE * (TH - 1) + 3, XPIX = XW * XH;
+    constexpr int XROWB = C * 2, YROWB = NB * 2;
+    constexpr int XPPI = 1024 / XROWB, YPPI = 1024 / YROWB;
+    constexpr int X_INSTR = (XPIX + XPPI - 1) / XPPI, Y_INSTR = TH * TW / YPPI;
+    constexpr int X_BYTES = X_INSTR * 1024;
+    constexpr int WC = C / 16, WN = 4 / WC;                // waves along the (tap, c) columns / along n
+    constexpr int NT = NB / 16 / WN, CT = 9;               // 16 x 16 accumulator tiles per wave: 2 x 9 (Cin = 32) or 4 x 9 (Cin = 64)
+    static_assert(9 * (C / 16) == WC * CT && WN * WC == 4, "nine column tiles per wave");
+    static_assert((TH - 1) * STRIDE * XW * XROWB + 4 * XROWB < 65536 && (TH - 1) * 32 * YROWB + 4 * YROWB < 65536, "ds_read immediates");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs = smem;
+    char* const ys = smem + X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w / WC, wc = w % WC;
+    const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    int run, nh;
+    if (NH == 1) {
+        run = blockIdx.x;
+        nh = 0;
+    } else {                                               // both halves of a run on one XCD (they read the same input pixels), back to back
+        const int t = blockIdx.x >> 3;
+        nh = t & 1;
+        run = (t >> 1) * 8 + (blockIdx.x & 7);
+        if (run >= p.runs) return;
+    }
+
+    auto xswz = [](int lcol) { return C == 32 ? (lcol >> 3) & 1 : ((lcol >> 1) & 1) | (((lcol >> 3) & 1) << 1); };
+    auto yswz = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); };
+    const uint32_t lds_x = (uint32_t)(size_t)LDS_PTR(xs), lds_y = (uint32_t)(size_t)LDS_PTR(ys);
+
+    // fragment addresses of patch row 0 (lo: pixels 8g + q, hi: + 4); row r adds an immediate
+    uint32_t ya[NT], xa[CT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row0 = 8 * g + q;
+        ya[nt] = lds_y + row0 * YROWB + (((wn * NT + nt) ^ yswz(row0)) << 5) + pp * 8;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int gct = wc * CT + ct;                      // global column tile = (tap, 16-channel block)
+        const int tap = gct / (C / 16), blk = gct % (C / 16);
+        const int tyy = tap / 3, txx = tap - 3 * tyy;
+        const int off = STRIDE == 1 ? txx : (txx & 1) * (XW / 2) + (txx >> 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lcol = off + 8 * g + q + 4 * h;
+            xa[ct][h] = lds_x + (tyy * XW + lcol) * XROWB + ((blk ^ xswz(lcol)) << 5) + pp * 8;
+        }
+    }
+
+    f32x4 acc[NT][CT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int t_begin = run * p.per_block;
+    const int t_end = t_begin + p.per_block < p.tiles ? t_begin + p.per_block : p.tiles;
+    const int Hx = p.x_img / p.x_row;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int b = (int)fd_div((uint32_t)tile, p.div_img);
+        const int trem = tile - b * (p.tx * p.ty);
+        const int tyi = (int)fd_div((uint32_t)trem, p.div_tx), txi = trem - tyi * p.tx;
+        const int oy0 = tyi * TH, ox0 = txi * TW;
+        __syncthreads();                                   // every wave is done reading the previous patch
+#if FVA_PWGRAD_ABL >= 2
+        if (tile == t_begin)
+#endif
+        {
+        // ---- stage X: LDS row py * XW + lcol <- padded input pixel (STRIDE * oy0 + x_y0 + py, STRIDE * ox0 + x_x0 + px) ----
+        {
+            const bf16_t* src0 = (const bf16_t*)p.x + (int64_t)b * p.x_img * C;
+#pragma unroll 1
+            for (int i = 0; i < (X_INSTR + 3) / 4; ++i) {
+                const int j = i * 4 + w;
+                if (j < X_INSTR) {
+                    const int row = j * XPPI + lane / (XROWB / 16);
+                    const int pix = row < XPIX ? row : XPIX - 1;
+                    const int py = STRIDE == 1 ? (pix * 1928) >> 16 : (pix * 993) >> 16;       // / 34, / 66
+                    const int lcol = pix - py * XW;
+                    const int px = STRIDE == 1 ? lcol : (lcol < XW / 2 ? 2 * lcol : 2 * (lcol - XW / 2) + 1);
+                    int iy = STRIDE * oy0 + p.x_y0 + py, ix = STRIDE * ox0 + p.x_x0 + px;
+                    iy = iy < Hx ? iy : Hx - 1;
+                    ix = ix < p.x_row ? ix : p.x_row - 1;
+                    const int chunk = (lane % (XROWB / 16)) ^ (xswz(lcol) << 1);
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + ((int64_t)iy * p.x_row + ix) * C + chunk * 8), LDS_PTR(xs + j * 1024), 16, 0, 0);
+                }
+            }
+        }
+        // ---- stage dY: output pixels (oy0 + r, ox0 + k), this block's 64 channels; pixels outside the image read the zero halo ----
+        {
+            const bf16_t* src0 = (const bf16_t*)p.dy + (int64_t)b * p.dy_img * NTOT + nh * NB;
+#pragma unroll 1
+            for (int i = 0; i < (Y_INSTR + 3) / 4; ++i) {
+                const int j = i * 4 + w;
+                if (j < Y_INSTR) {
+                    const int row = j * YPPI + lane / (YROWB / 16);                  // r * 32 + k
+                    const int oy = oy0 + (row >> 5), ox = ox0 + (row & 31);
+                    const bool in = oy < p.OH && ox < p.OW;
+                    const int64_t pix = in ? (int64_t)(oy + p.dy_pad) * p.dy_row + ox + p.dy_pad : 0;   // (0, 0) of the padded image: zero
+                    const int chunk = (lane % (YROWB / 16)) ^ (yswz(row) << 1);
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src0 + pix * NTOT + chunk * 8), LDS_PTR(ys + j * 1024), 16, 0, 0);
+                }
+            }
+        }
+        }
+        wait_vm0();
+        __syncthreads();
+        // ---- TH k-steps of 32 pixels (one patch row each) ----
+#if FVA_PWGRAD_ABL != 1
+        static_for<0, TH>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int XO = r * STRIDE * XW * XROWB, YO = r * 32 * YROWB;
+            // column tiles in groups of CG: the 64-channel form holds 144 accumulators, and nine B fragments on top of them spill
+            constexpr int CG = C == 32 ? 9 : 5;
+            bf16x8 af[NT];
+#if FVA_PWGRAD_ABL == 3
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) af[nt] = __builtin_bit_cast(bf16x8, u32x4{ya[nt], ya[nt] + r, ya[nt], ya[nt]});
+#else
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) af[nt] = cat8(tr_read<YO>(ya[nt]), tr_read<YO + 4 * YROWB>(ya[nt]));
+#endif
+#pragma unroll
+            for (int c0 = 0; c0 < CT; c0 += CG) {
+                bf16x8 bfr[CG];
+#pragma unroll
+#if FVA_PWGRAD_ABL == 3
+                for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) bfr[ct - c0] = __builtin_bit_cast(bf16x8, u32x4{xa[ct][0], xa[ct][1], xa[ct][0] + r, xa[ct][1]});
+#else
+                for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) bfr[ct - c0] = cat8(tr_read<XO>(xa[ct][0]), tr_read<XO>(xa[ct][1]));
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#if FVA_PWGRAD_ABL == 4
+#pragma unroll
+                for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) acc[0][ct] += __builtin_bit_cast(f32x4, bfr[ct - c0]) + __builtin_bit_cast(f32x4, af[ct % NT]);
+#else
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct)
+                        acc[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[ct - c0], acc[nt][ct], 0, 0, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+#endif
+    }
+    // ---- partial gradient -> slab[run][tap][Cout][Cin] ----
+    float* out = p.slab + (int64_t)run * 9 * NTOT * C;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int gct = wc * CT + ct;
+            const int tap = gct / (C / 16), c = (gct % (C / 16)) * 16 + i16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nh * NB + (wn * NT + nt) * 16 + g * 4 + j;
+                slab_store(out + ((int64_t)tap * NTOT + n) * C + c, acc[nt][ct][j]);
+            }
+        }
+}
+
 // dw[n][c][t] (+)= sum_ks slab[ks][t][n][c].  Block = 64 consecutive (n,c) pairs x 4 split-K groups: every load is
 // a coalesced 256-B row of the slab, partial sums are combined in a fixed order (deterministic), and the k*k taps
 // of the 64 pairs leave as one contiguous run of the OIHW gradient.
@@ -622,6 +841,45 @@ __global__ __launch_bounds__(1024) void wgrad_reduce4_kernel(const float* __rest
     }
 }
 
+// The reduction for the all-taps kernel's slabs: few (n,c) pairs (2048 or 8192) but 256-512 split-K runs, so wgrad_reduce4_kernel's
+// grid -- one block per 256 pairs, all taps -- is 8 or 32 blocks that each pull 1-5 MiB through one CU: ~70 us for the 32 -> 64
+// layers, a third of the weight gradient's time (tools/thin_pwgrad_abl.sh).  Here a block owns 256 pairs of ONE tap (grid.y = 9)
+// and its 16 waves take every 16th run, eight 1-KiB rows in flight each; partial sums are combined in wave order (deterministic).
+__global__ __launch_bounds__(1024) void wgrad_reduce_tap_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t nc, int ksplit,
+                                                                int accumulate) {
+    __shared__ f32x4 part[16][64];
+    const int t = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int li = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = i0 + li * 4;
+    const int64_t kstride = 9 * nc;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < nc) {
+        const float* src = slab + (int64_t)t * nc + i;
+        int k = w;
+        for (; k + 7 * 16 < ksplit; k += 8 * 16) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (int64_t)(k + u * 16) * kstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < ksplit; k += 16) s += *(const f32x4*)(src + (int64_t)k * kstride);
+    }
+    part[w][li] = s;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int l = threadIdx.x;
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += part[g][l >> 2][l & 3];
+        if (i0 + l < nc) {
+            float* o = dw + (i0 + l) * 9 + t;
+            *o = accumulate ? *o + a : a;
+        }
+    }
+}
+
 struct WgradPlan {
     int tile, ntn, ntc, ntaps, ksplit, mchunk, M, OH, OW, tpt, ngroups;
 };
@@ -698,6 +956,70 @@ int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl, bool beside = false) {
     return FVA_OK;
 }
 
+// the all-taps kernel: thin 3x3 bf16 layers on maps at least one patch wide.  FVA_PWGRAD=0 switches it off.
+inline bool use_pwgrad(const fva_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("FVA_PWGRAD"); return !e || atoi(e) != 0; }();
+    if (!on || d->dtype != FVA_BF16 || d->ksize != 3 || !((d->Cin == 32 && d->Cout == 64) || (d->Cin == 64 && d->Cout == 128))) return false;
+    const int OW = (d->W - 1) / d->stride + 1, OH = (d->H - 1) / d->stride + 1;
+    return OW >= 32 && OH >= 8 && d->in_pad >= 1 && d->dy_pad >= 1;
+}
+struct PwgradPlan {
+    int th, tx, ty, tiles, runs, per_block, grid;
+};
+// patch rows: 8 (stride 1), 4 (stride 2, Cin = 32), 2 (stride 2, Cin = 64: the 4-row patch is 92 KiB of LDS, one block per CU -- 272 against
+// 211 us).  FVA_PWGRAD_TH=<stride-1 rows>,<stride-2 rows> forces the other instantiations (8 or 4, 4 or 2; tools/thin_pwgrad.sh).
+inline int pwgrad_th(const fva_conv_desc* d) {
+    static int th1 = 0, th2 = 0;
+    static const bool init = [] {
+        const char* e = getenv("FVA_PWGRAD_TH");
+        if (e) {
+            int a = 0, b = 0;
+            const int n = sscanf(e, "%d,%d", &a, &b);
+            if (n >= 1 && (a == 8 || a == 4)) th1 = a;
+            if (n >= 2 && (b == 4 || b == 2)) th2 = b;
+        }
+        return true;
+    }();
+    (void)init;
+    if (d->stride == 1) return th1 ? th1 : 8;
+    return th2 ? th2 : (d->Cin == 64 ? 2 : 4);
+}
+inline void plan_pwgrad(const fva_conv_desc* d, PwgradPlan& pl, bool beside) {
+    const int OH = (d->H - 1) / d->stride + 1, OW = (d->W - 1) / d->stride + 1;
+    pl.th = pwgrad_th(d);
+    pl.tx = cdiv(OW, 32);
+    pl.ty = cdiv(OH, pl.th);
+    pl.tiles = d->B * pl.tx * pl.ty;
+    const int nh = d->Cout / 64;
+    static const int per_cu = [] { const char* e = getenv("FVA_PWGRAD_SLOTS"); return e ? atoi(e) : 2; }();
+    int slots = 256 * per_cu / nh;                  // resident runs: two 4-wave blocks per CU, a run of a 128-channel layer is two blocks
+    if (beside) slots /= 2;                         // beside the launch stream: plan_wgrad
+    const int runs = pl.tiles < slots ? pl.tiles : slots;
+    pl.per_block = cdiv(pl.tiles, runs);
+    pl.runs = cdiv(pl.tiles, pl.per_block);
+    pl.grid = nh == 1 ? pl.runs : cdiv(pl.runs, 8) * 16;
+}
+
+template <int C, int N, int STRIDE, int TH>
+int launch_pwgrad(const PwgradParams& p, int grid, hipStream_t s) {
+    constexpr int XPIX = (STRIDE * 32 + 2) * (STRIDE * (TH - 1) + 3);
+    constexpr int XPPI = 1024 / (C * 2);
+    constexpr int smem = ((XPIX + XPPI - 1) / XPPI) * 1024 + (TH * 32 / 8) * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)pwgrad_kernel<C, N, STRIDE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pwgrad_kernel<C, N, STRIDE, TH>), dim3(grid), dim3(256), smem, s, p);
+    FVA_LAUNCH_CHECK("pwgrad_kernel");
+    return FVA_OK;
+}
+template <int C, int N>
+int launch_pwgrad_any(const PwgradParams& p, int stride, int th, int grid, hipStream_t s) {
+    if (stride == 1) return th == 8 ? launch_pwgrad<C, N, 1, 8>(p, grid, s) : launch_pwgrad<C, N, 1, 4>(p, grid, s);
+    return th == 4 ? launch_pwgrad<C, N, 2, 4>(p, grid, s) : launch_pwgrad<C, N, 2, 2>(p, grid, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -707,7 +1029,13 @@ int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d) {
     WgradPlan pl, pb;
     plan_wgrad(d, pl, false);
     plan_wgrad(d, pb, true);          // whichever stream the launch will be given
-    return (int64_t)(pl.ksplit > pb.ksplit ? pl.ksplit : pb.ksplit) * pl.ntaps * d->Cout * d->Cin * 4;
+    int ks = pl.ksplit > pb.ksplit ? pl.ksplit : pb.ksplit;
+    if (use_pwgrad(d)) {
+        PwgradPlan pp;
+        plan_pwgrad(d, pp, false);
+        ks = ks > pp.runs ? ks : pp.runs;
+    }
+    return (int64_t)ks * pl.ntaps * d->Cout * d->Cin * 4;
 }
 
 int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
@@ -725,8 +1053,34 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         (int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cout * esz >= (1ll << 32))
         return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
-    plan_wgrad(d, pl, stream != nullptr && (hipStream_t)stream == fva_side_stream_peek());
+    const bool beside = stream != nullptr && (hipStream_t)stream == fva_side_stream_peek();
+    plan_wgrad(d, pl, beside);
     FvaProfileSpan span(2 | (d->ksize << 8), 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    if (use_pwgrad(d)) {
+        PwgradPlan pp;
+        plan_pwgrad(d, pp, beside);
+        const int64_t need = (int64_t)pp.runs * 9 * d->Cout * d->Cin * 4;
+        if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_conv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
+        PwgradParams q = PwgradParams();
+        q.x = x; q.dy = dy; q.slab = (float*)workspace;
+        q.B = d->B; q.OH = pl.OH; q.OW = pl.OW;
+        q.x_row = d->W + 2 * d->in_pad;
+        q.x_img = (d->H + 2 * d->in_pad) * q.x_row;
+        q.x_y0 = q.x_x0 = d->in_pad - 1;
+        q.dy_row = pl.OW + 2 * d->dy_pad;
+        q.dy_img = (pl.OH + 2 * d->dy_pad) * q.dy_row;
+        q.dy_pad = d->dy_pad;
+        q.tx = pp.tx; q.ty = pp.ty; q.tiles = pp.tiles; q.per_block = pp.per_block; q.runs = pp.runs;
+        q.div_tx = make_fastdiv(pp.tx);
+        q.div_img = make_fastdiv(pp.tx * pp.ty);
+        hipStream_t s = (hipStream_t)stream;
+        const int rc = d->Cin == 32 ? launch_pwgrad_any<32, 64>(q, d->stride, pp.th, pp.grid, s) : launch_pwgrad_any<64, 128>(q, d->stride, pp.th, pp.grid, s);
+        if (rc) return rc;
+        const int64_t nc = (int64_t)d->Cout * d->Cin;
+        hipLaunchKernelGGL(wgrad_reduce_tap_kernel, dim3((int)((nc + 255) / 256), 9), dim3(1024), 0, s, (const float*)workspace, dw, nc, pp.runs, accumulate);
+        FVA_LAUNCH_CHECK("wgrad_reduce_tap_kernel");
+        return FVA_OK;
+    }
     const int64_t need = (int64_t)pl.ksplit * pl.ntaps * d->Cout * d->Cin * 4;
     if (workspace_bytes < need) return fva_fail(FVA_ERR_WORKSPACE, "fva_conv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
     WgradParams p = WgradParams();

@@ -11,9 +11,16 @@ import json
 import re
 import sys
 
-CLASSES = {'conv_fwd': lambda n: ('igemm_kernel' in n and re.search(r'ELi0ELi\d+EEE', n)) or 'igemm8_kernelILi0' in n or 'igemm8_kernel<0' in n,
+def _epi(n, kernel):
+    """epilogue template argument of a patch-kernel instance name (demangled or mangled), or None"""
+    m = re.search(kernel + r'<\d+, \d+, \d+, (\d)>', n) or re.search(kernel + r'ILi\d+ELi\d+ELi\d+ELi(\d)EEE', n)
+    return int(m.group(1)) if m else None
+
+
+CLASSES = {'conv_fwd': lambda n: ('igemm_kernel' in n and re.search(r'ELi0ELi\d+EEE', n)) or 'igemm8_kernelILi0' in n or 'igemm8_kernel<0' in n
+                                 or _epi(n, 'pconv_kernel') == 0,
            'conv_dgrad': lambda n: ('igemm_kernel' in n and re.search(r'ELi[14]ELi\d+EEE', n)) or 'igemm8_kernelILi1' in n or 'igemm8_kernel<1' in n
-                                   or 'igemm8_kernelILi4' in n or 'igemm8_kernel<4' in n,
+                                   or 'igemm8_kernelILi4' in n or 'igemm8_kernel<4' in n or _epi(n, 'pconv_kernel') in (1, 4) or 'pdgrad2_kernel' in n,
            'conv_wgrad': lambda n: 'wgrad_kernel' in n or 'wgrad8_kernel' in n or 'wgrad_reduce_kernel' in n or 'wgrad_reduce4_kernel' in n}
 
 
