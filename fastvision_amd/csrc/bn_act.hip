@@ -314,21 +314,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h) {
+                                                           const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h, int nrows) {
     constexpr int EPC = Vec16<T>::N, U = FVA_BN_UNROLL;
-    const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
-    const int yy = yp - h.pad;
-    const bool row_in = yy >= 0 && yy < h.H;
     const int row_chunks = h.Wp * h.cpp;
-    T* orow = dy + (int64_t)blockIdx.x * row_chunks * EPC;
-    if (!row_in) {
-        Vec16<T> zero;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
-        for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(orow + (int64_t)i * EPC) = zero;
-        return;
-    }
-    const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);
     // lane-constant channel chunk (cpp divides 256): dY = a*dU + k1*y + k2 with k1 = coefB*rstd, k2 = coefC - k1*mean
     const int cc = threadIdx.x & cmask;
@@ -342,29 +330,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k1[e] = coef[h.C + c] * rstd[c];
         k2[e] = coef[2 * h.C + c] - k1[e] * mean[c];
     }
-    for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
-        Vec16<T> g[U], v[U];
-        bool ok[U];
+    // one padded row per block, or (EXPERIMENT FVA_APPLY_PERSIST: a grid of a few blocks per CU) a strided set of rows
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int b = row / h.Hp, yp = row - b * h.Hp;
+        const int yy = yp - h.pad;
+        const bool row_in = yy >= 0 && yy < h.H;
+        T* orow = dy + (int64_t)row * row_chunks * EPC;
+        if (!row_in) {
+            Vec16<T> zero;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 256;
-            const int xx = (i >> cshift) - h.pad;
-            ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
-            const int64_t off = (m0 + (ok[u] ? xx : 0)) * h.C + cc * EPC;
-            g[u] = ld_last<T>(dz + off);
-            v[u] = ld_last<T>(y + off);
+            for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
+            for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(orow + (int64_t)i * EPC) = zero;
+            continue;
         }
+        const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
+        for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
+            Vec16<T> g[U], v[U];
+            bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 256;
-            Vec16<T> out;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float yv = v[u].get(e);
-                const float du = g[u].get(e) * silu_grad(yv * sc[e] + sh[e]);
-                out.set(e, ok[u] ? ka[e] * du + k1[e] * yv + k2[e] : 0.f);
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                const int xx = (i >> cshift) - h.pad;
+                ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
+                const int64_t off = (m0 + (ok[u] ? xx : 0)) * h.C + cc * EPC;
+                g[u] = ld_last<T>(dz + off);
+                v[u] = ld_last<T>(y + off);
             }
-            if (i < row_chunks) *(Vec16<T>*)(orow + (int64_t)i * EPC) = out;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                Vec16<T> out;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float yv = v[u].get(e);
+                    const float du = g[u].get(e) * silu_grad(yv * sc[e] + sh[e]);
+                    out.set(e, ok[u] ? ka[e] * du + k1[e] * yv + k2[e] : 0.f);
+                }
+                if (i < row_chunks) *(Vec16<T>*)(orow + (int64_t)i * EPC) = out;
+            }
         }
     }
 }
@@ -624,12 +627,17 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
     // EXPERIMENT (FVA_APPLY_LDS=bytes): an unused dynamic LDS allocation caps the blocks per CU (160 KiB / bytes), so that a
     // weight-gradient block of the low-priority side stream (64 KiB, one wave per SIMD) finds LDS and registers beside this pass
     static const int cap_lds = [] { const char* e = getenv("FVA_APPLY_LDS"); return e ? atoi(e) : 0; }();
+    // EXPERIMENT (FVA_APPLY_PERSIST=k): a grid of k blocks per CU that walk the rows, so that the launch stream has no block
+    // PENDING while the pass runs and the dispatcher can place the side stream's low-priority blocks beside it
+    static const int persist = [] { const char* e = getenv("FVA_APPLY_PERSIST"); return e ? atoi(e) : 0; }();
+    const int nrows = B * h.Hp;
+    const int grid = persist > 0 && nrows > 256 * persist ? 256 * persist : nrows;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), cap_lds, s, (const bf16_t*)dz, (const bf16_t*)y,
-                           scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), cap_lds, s, (const bf16_t*)dz, (const bf16_t*)y,
+                           scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h, nrows);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(B * h.Hp), dim3(256), cap_lds, s, (const float*)dz, (const float*)y,
-                           scale, shift, save_mean, save_rstd, coef, (float*)dy, h);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), cap_lds, s, (const float*)dz, (const float*)y,
+                           scale, shift, save_mean, save_rstd, coef, (float*)dy, h, nrows);
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return FVA_OK;
 }

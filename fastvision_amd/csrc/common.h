@@ -94,6 +94,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15): four rotations, every lane of the row ends with the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    return v;
+}
+
+// two floats -> packed bf16 pair (round to nearest even), one instruction
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // zero border of a halo NHWC buffer [B][H+2p][W+2p][C] given in 16-byte pieces per pixel (errors.hip)

@@ -257,7 +257,9 @@ struct Acc<float> {  // per wave 64x64 = 2x2 tiles of 32x32
     f32x16 a[2][2];
 };
 
-// visit every accumulator element with its (row, col) inside the wave's 64x64 tile
+// visit every accumulator element with its (row, col) inside the wave's 64x64 tile.  bf16: the kernel issues its MFMAs with the
+// operands swapped (D^T = B^T A^T), so that lane (r, g) holds of tile (mt, nt) the 1 x 4 piece  row mt*16 + r, columns nt*16 + 4g .. +3
+// -- four adjacent output channels of one pixel, one 8-byte LDS write in the epilogue instead of four 2-byte ones.
 template <typename F>
 __device__ __forceinline__ void foreach_acc(Acc<bf16_t>& acc, int lane, F&& f) {
     const int r = lane & 15, g = lane >> 4;
@@ -266,7 +268,7 @@ __device__ __forceinline__ void foreach_acc(Acc<bf16_t>& acc, int lane, F&& f) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) f(mt * 16 + g * 4 + j, nt * 16 + r, nt, acc.a[mt][nt][j]);
+            for (int j = 0; j < 4; ++j) f(mt * 16 + r, nt * 16 + g * 4 + j, nt, acc.a[mt][nt][j]);
 }
 template <typename F>
 __device__ __forceinline__ void foreach_acc(Acc<float>& acc, int lane, F&& f) {
@@ -488,7 +490,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
-                        acc.a[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc.a[mt][nt], 0, 0, 0);
+                        acc.a[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc.a[mt][nt], 0, 0, 0);   // swapped: see foreach_acc
             }
         } else {
             const int r = lane & 31, h = lane >> 5, sr = (r >> 1) & 7;
@@ -529,38 +531,62 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     // ---- BatchNorm partial statistics: per-column sum and sum of squares over this block's valid rows ----
     if constexpr (EPI == EPI_STATS) {
         if (p.stats != nullptr) {
-            constexpr int NT = IS_BF16 ? 4 : 2;
-            float s1[NT], s2[NT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
             // statistics of the fp32 accumulators (the bf16 rounding of the stored tile is zero-mean, 2^-9 relative:
             // far below the batch-statistics noise); full tiles take the mask-free path
-            if (m0 + BM <= p.M) {
-                foreach_acc(acc, lane, [&](int, int, int nt, float v) {
-                    s1[nt] += v;
-                    s2[nt] += v * v;
-                });
-            } else {
-                foreach_acc(acc, lane, [&](int row, int, int nt, float v) {
-                    const float x = (m0 + wrow0 + row < p.M) ? v : 0.f;
-                    s1[nt] += x;
-                    s2[nt] += x * x;
-                });
-            }
-            float* red = (float*)smem;  // [2][BM/64][BN]
             constexpr int WMc = BM / 64;
+            if constexpr (IS_BF16) {
+                // a lane's accumulators are 16 rows (mt, r fixed) x 16 columns (nt, j): column sums over mt in registers, then the
+                // 16 lane rows r and the BM / 64 wave rows through LDS, added by the column's thread in a fixed order
+                const int r = lane & 15, g = lane >> 4;
+                f32x4 s1[4], s2[4];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                if constexpr (IS_BF16) {
-                    s1[i] += __shfl_xor(s1[i], 16);
-                    s1[i] += __shfl_xor(s1[i], 32);
-                    s2[i] += __shfl_xor(s2[i], 16);
-                    s2[i] += __shfl_xor(s2[i], 32);
-                    if (lane < 16) {
-                        red[(0 * WMc + wr) * BN + wcol0 + i * 16 + lane] = s1[i];
-                        red[(1 * WMc + wr) * BN + wcol0 + i * 16 + lane] = s2[i];
+                for (int nt = 0; nt < 4; ++nt) s1[nt] = s2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool whole = m0 + BM <= p.M;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bool live = whole || m0 + wrow0 + mt * 16 + r < p.M;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const f32x4 v = live ? acc.a[mt][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        s1[nt] += v;
+                        s2[nt] += v * v;
                     }
+                }
+                float* red = (float*)smem;  // [2][BM/64][16][RP]
+                constexpr int RP = BN + 4;  // rows 16 bytes apart in the banks
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    *(f32x4*)(red + ((0 * WMc + wr) * 16 + r) * RP + wcol0 + nt * 16 + 4 * g) = s1[nt];
+                    *(f32x4*)(red + ((1 * WMc + wr) * 16 + r) * RP + wcol0 + nt * 16 + 4 * g) = s2[nt];
+                }
+                __syncthreads();
+                if (w < BN / 32) {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
+                    const int which = lane >> 5, col = w * 32 + (lane & 31);
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WMc * 16; ++k) s += red[(which * WMc * 16 + k) * RP + col];
+                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                }
+                __syncthreads();
+            } else {
+                float s1[2], s2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) s1[i] = s2[i] = 0.f;
+                if (m0 + BM <= p.M) {
+                    foreach_acc(acc, lane, [&](int, int, int nt, float v) {
+                        s1[nt] += v;
+                        s2[nt] += v * v;
+                    });
                 } else {
+                    foreach_acc(acc, lane, [&](int row, int, int nt, float v) {
+                        const float x = (m0 + wrow0 + row < p.M) ? v : 0.f;
+                        s1[nt] += x;
+                        s2[nt] += x * x;
+                    });
+                }
+                float* red = (float*)smem;  // [2][BM/64][BN]
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
                     s1[i] += __shfl_xor(s1[i], 32);
                     s2[i] += __shfl_xor(s2[i], 32);
                     if (lane < 32) {
@@ -568,16 +594,16 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                         red[(1 * WMc + wr) * BN + wcol0 + i * 32 + lane] = s2[i];
                     }
                 }
-            }
-            __syncthreads();
-            if (w < BN / 32) {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
-                const int which = lane >> 5, col = w * 32 + (lane & 31);
-                float s = 0.f;
+                __syncthreads();
+                if (w < BN / 32) {
+                    const int which = lane >> 5, col = w * 32 + (lane & 31);
+                    float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
-                if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                    for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
+                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 
@@ -674,13 +700,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             static_assert(4 * BN <= NT || EPI != EPI_BNB || COEF_BYTES > 0, "one table entry per thread");
             if (tid < 4 * BN) coef_v[0] = bnb_coef_at<BN, NT>(p, tid, n0);
         }
-        foreach_acc(acc, lane, [&](int row, int col, int, float v) {
-            if constexpr (EPI == EPI_BNACT) {
-                const int n = n0 + wcol0 + col < p.N ? n0 + wcol0 + col : p.N - 1;
-                v = bnact_f(p, v, n);
-            }
-            *(bf16_t*)(smem + (wrow0 + row) * PITCH + (wcol0 + col) * 2) = (bf16_t)v;
-        });
+        {
+            const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 v = acc.a[mt][nt];
+                    const int col = wcol0 + nt * 16 + 4 * g;
+                    if constexpr (EPI == EPI_BNACT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = bnact_f(p, v[j], n0 + col + j < p.N ? n0 + col + j : p.N - 1);
+                    }
+                    *(u32x2*)(smem + (wrow0 + mt * 16 + r) * PITCH + col * 2) = u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+                }
+        }
         if constexpr (EPI == EPI_BNB && COEF_BYTES == 0) {
             if (tid < 4 * BN) coef_tab[tid] = coef_v[0];
         }
@@ -1258,6 +1292,7 @@ struct StreamK {
     int32_t tiles;
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8], see the kernel's stamp()
     int stamp_rows;      // blocks beyond the caller's buffer do not stamp
+    int skew;            // EXPERIMENT (FVA_IGEMM8_SKEW): every other first-round block of an XCD starts this many x 8128 cycles late
 };
 
 // MT = 16-row accumulator tiles per wave along m: 8 (a 256-row block) or 7 (224 rows).  At B = 32 the eligible layers have
@@ -1265,6 +1300,9 @@ struct StreamK {
 // tiles give 915 / 458 / 232: the same number of rounds of tiles that each cost 7/8 of the MFMA work (use_igemm8_mt picks).  The
 // LDS image keeps its 128-row half-tiles (the second half of a wave row holds 48 live rows; the other 16 are staged and never
 // read), so the staging, the swizzle and every hazard argument above are unchanged.
+#ifndef FVA_EPI_STAMPS
+#define FVA_EPI_STAMPS 0     // 1: the four diagnostic stamps bracket the epilogue's phases instead of the tile's (tools/tile_timing.py)
+#endif
 template <int EPI, bool SK, int MT>
 __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const StreamK sk) {
     static_assert(MT >= 5 && MT <= 8, "4 tiles in the first half of a wave row, 1-4 in the second");
@@ -1282,9 +1320,13 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             sk.stamps[(int64_t)blockIdx.x * 8 + 4 + i] = clock64();
         }
     };
+#if !FVA_EPI_STAMPS
     stamp(0);
+#endif
 
     const int nwg = gridDim.x, bid = blockIdx.x;
+    if (sk.skew && bid < 256 && ((bid >> 3) & 1))        // the rounds of the two halves then store their tiles at different times
+        for (int i = 0; i < sk.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int KT = p.ktiles;
@@ -1401,8 +1443,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
                         if (ha * 4 + mt < MT)
-                            acc[ha * 4 + mt][hb * 2 + nt] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+                            acc[ha * 4 + mt][hb * 2 + nt] =      // operands swapped: D = (B^T A^T), a lane's four accumulators are four adjacent COLUMNS
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][ks], af[mt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
         auto retire_reads_then_barrier = [&]() {
@@ -1427,7 +1469,9 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+#if !FVA_EPI_STAMPS
         stamp(1);
+#endif
         if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
         for (int t = kt0; t < kt1; ++t) {
@@ -1467,7 +1511,11 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
         __syncthreads();                             // LDS is free for the epilogue
+#if FVA_EPI_STAMPS
+        stamp(0);
+#else
         stamp(2);
+#endif
         // everything below derives its addresses from this copy: computed after the loop, not carried (spilled) through it
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
@@ -1524,44 +1572,44 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             }
         }
 
-        // visit the wave's 128x64 accumulator: (row, col) inside the block tile
-        auto foreach = [&](auto&& f) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f(wr_e * WM + mi * 16 + g_e * 4 + j, wc_e * 64 + ni * 16 + r_e, ni, acc[mi][ni][j]);
-        };
+        // The wave's 128x64 accumulator.  With the MFMA operands swapped, acc[mi][ni] of lane (r, g) is the 1 x 4 piece
+        //   row  wr * WM + mi * 16 + r,   columns  wc * 64 + ni * 16 + 4 g .. + 3
+        // of the block tile: four adjacent output channels of one pixel -- one packed 8-byte LDS write instead of four 2-byte ones
+        // (the unswapped layout, four ROWS of one column per lane, cost 128 ds_write_b16 per lane: 2.0 of the epilogue's 7.5 us).
+        const int row_e = wr_e * WM + r_e, col_e = wc_e * 64 + 4 * g_e;
 
         if constexpr (EPI == EPI_STATS) {
             if (p.stats != nullptr) {
-                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (m0 + BM <= p.M) {
-                    foreach([&](int, int, int ni, float v) { s1[ni] += v; s2[ni] += v * v; });
-                } else {
-                    foreach([&](int row, int, int ni, float v) {
-                        const float x = (m0 + row < p.M) ? v : 0.f;
-                        s1[ni] += x;
-                        s2[ni] += x * x;
-                    });
-                }
-                float* red = (float*)smem;  // [2][2 (wr)][BN]
+                f32x4 s1[4], s2[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s1[i] += __shfl_xor(s1[i], 16);
-                    s1[i] += __shfl_xor(s1[i], 32);
-                    s2[i] += __shfl_xor(s2[i], 16);
-                    s2[i] += __shfl_xor(s2[i], 32);
-                    if (lane_e < 16) {
-                        red[(0 * 2 + wr_e) * BN + wc_e * 64 + i * 16 + lane_e] = s1[i];
-                        red[(1 * 2 + wr_e) * BN + wc_e * 64 + i * 16 + lane_e] = s2[i];
+                for (int ni = 0; ni < 4; ++ni) s1[ni] = s2[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool whole = m0 + BM <= p.M;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const bool live = whole || m0 + row_e + mi * 16 < p.M;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4 v = live ? acc[mi][ni] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        s1[ni] += v;
+                        s2[ni] += v * v;
                     }
+                }
+                // the sum over the 16 lane rows r goes through LDS: every lane leaves its 2 x 16 partial sums (eight 16-byte writes) and
+                // the column's thread adds the 2 (wr) x 16 (r) pieces in a fixed order -- 32 reads and adds per thread instead of 256
+                // cross-lane operations (four DPP steps on 32 values, which the compiler does not fuse into the adds)
+                float* red = (float*)smem;  // [2 (sum, sum of squares)][2 (wr)][16 (r)][RP]: 65 KiB of the dead staging buffers
+                constexpr int RP = BN + 4;  // rows 16 bytes apart in the banks: the 16 lanes r of a 16-byte write hit 64 distinct banks
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    *(f32x4*)(red + ((0 * 2 + wr_e) * 16 + r_e) * RP + col_e + ni * 16) = s1[ni];
+                    *(f32x4*)(red + ((1 * 2 + wr_e) * 16 + r_e) * RP + col_e + ni * 16) = s2[ni];
                 }
                 __syncthreads();
                 {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
                     const int which = lane_e >> 5, col = (tid_e >> 6) * 32 + (lane_e & 31);
-                    const float s = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) s += red[(which * 32 + i) * RP + col];
                     if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
                 }
                 __syncthreads();
@@ -1578,11 +1626,24 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         };
         // bf16 tile through LDS so that every row leaves as 16-byte pieces
         constexpr int PITCH = BN * 2 + 16;
-        foreach([&](int row, int col, int, float v) {
-            if constexpr (EPI == EPI_BNACT) v = bnact_f(p, v, n0 + col);
-            *(bf16_t*)(smem + row * PITCH + col * 2) = (bf16_t)v;
-        });
+#if FVA_EPI_STAMPS
+        stamp(1);
+#endif
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[mi][ni];
+                if constexpr (EPI == EPI_BNACT) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = bnact_f(p, v[j], n0 + col_e + ni * 16 + j);
+                }
+                *(u32x2*)(smem + (row_e + mi * 16) * PITCH + (col_e + ni * 16) * 2) = u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            }
         __syncthreads();
+#if FVA_EPI_STAMPS
+        stamp(2);
+#endif
         store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
                                                 nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
         if constexpr (EPI == EPI_STATS) {
@@ -1680,6 +1741,8 @@ int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     StreamK sk{};
     sk.stamps = g_stamps;
     sk.stamp_rows = g_stamp_rows;
+    static const int skew = [] { const char* e = getenv("FVA_IGEMM8_SKEW"); return e ? atoi(e) : 0; }();
+    sk.skew = tiles > 256 ? skew : 0;
     if (bm == 256 && use_streamk(tiles, p.ktiles)) {
         sk.slabs = g_sk.slabs;
         sk.flags = g_sk.flags;

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from fastvision_amd import _lib, ops
 
-SHAPES = [(32, 256, 512, 40, 3), (32, 512, 1024, 20, 3), (32, 512, 256, 40, 3)]      # (B, Cin, Cout, H, k); the last one is the 256->512 dgrad's shape run as a forward
+SHAPES = [(32, 128, 256, 80, 3), (32, 256, 512, 40, 3), (32, 512, 1024, 20, 3), (32, 512, 256, 40, 3)]      # (B, Cin, Cout, H, k); the last one is the 256->512 dgrad's shape run as a forward
 
 
 def main():
