@@ -107,11 +107,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// two floats -> packed bf16 pair (round to nearest even), one instruction
+// two floats -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32.  Through the compiler's own vector conversion, NOT
+// inline asm: an asm statement that reads an MFMA result is invisible to the hazard recognizer (no wait states are inserted between
+// the MFMA and the read) -- the patch kernels' plain epilogue, where only a barrier separates the two, produced NaNs that way.
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTILE; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTILE; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);   // swapped: foreach_acc
         }
     };
 
@@ -922,44 +922,40 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     }
     __syncthreads();   // LDS is free for the epilogue
 
-    // tile row of accumulator element (mt, j): patch pixel (2w + (mt >> 1), (mt & 1) * 16 + 4 g + j)
+    // accumulator tile (mt, nt) of lane (r16, g) (MFMA operands swapped, see foreach_acc): tile row = patch pixel
+    // (2w + (mt >> 1), (mt & 1) * 16 + r16), columns nt * 16 + 4 g .. + 3
     const bool full = (ty + 1) * TH <= p.pt_H && (tx + 1) * TW <= p.pt_W;
     auto row_ok = [&](int rr) { return ty * TH + (rr >> 5) < p.pt_H && tx * TW + (rr & 31) < p.pt_W; };
     if constexpr (EPI == EPI_STATS) {
         if (p.stats != nullptr) {
-            float s1[NTILE], s2[NTILE];
+            f32x4 s1[NTILE], s2[NTILE];
 #pragma unroll
-            for (int i = 0; i < NTILE; ++i) s1[i] = s2[i] = 0.f;
+            for (int i = 0; i < NTILE; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = full || row_ok((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + r16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = full || row_ok((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + g * 4 + j);
-#pragma unroll
-                    for (int nt = 0; nt < NTILE; ++nt) {
-                        const float v = ok ? acc[mt][nt][j] : 0.f;
-                        s1[nt] += v;
-                        s2[nt] += v * v;
-                    }
+                for (int nt = 0; nt < NTILE; ++nt) {
+                    const f32x4 v = ok ? acc[mt][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    s1[nt] += v;
+                    s2[nt] += v * v;
                 }
-            float* red = (float*)smem;  // [2][4 waves][BN]
+            }
+            // the 16 lane rows and the four waves through LDS, added by the column's thread in a fixed order (igemm_kernel's scheme)
+            float* red = (float*)smem;  // [2][4 waves][16][RP]: below the tile's end, clear of resident weights
+            constexpr int RP = BN + 4;
+            static_assert(2 * 4 * 16 * RP * 4 <= TILE_BYTES, "the statistics scratch stays inside the epilogue tile's bytes");
 #pragma unroll
-            for (int i = 0; i < NTILE; ++i) {
-                s1[i] += __shfl_xor(s1[i], 16);
-                s1[i] += __shfl_xor(s1[i], 32);
-                s2[i] += __shfl_xor(s2[i], 16);
-                s2[i] += __shfl_xor(s2[i], 32);
-                if (lane < 16) {
-                    red[(0 * 4 + w) * BN + i * 16 + lane] = s1[i];
-                    red[(1 * 4 + w) * BN + i * 16 + lane] = s2[i];
-                }
+            for (int nt = 0; nt < NTILE; ++nt) {
+                *(f32x4*)(red + ((0 * 4 + w) * 16 + r16) * RP + nt * 16 + 4 * g) = s1[nt];
+                *(f32x4*)(red + ((1 * 4 + w) * 16 + r16) * RP + nt * 16 + 4 * g) = s2[nt];
             }
             __syncthreads();
             if (w < BN / 32) {
                 const int which = lane >> 5, col = w * 32 + (lane & 31);
                 float t = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t += red[(which * 4 + k) * BN + col];
+                for (int k = 0; k < 64; ++k) t += red[(which * 64 + k) * RP + col];
                 if (col < p.N) st_agent(p.stats + ((int64_t)tile * 2 + which) * p.N + col, t);
             }
             __syncthreads();
@@ -968,10 +964,10 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTILE; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *(bf16_t*)(smem + ((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + g * 4 + j) * PITCH + (nt * 16 + r16) * 2) = (bf16_t)acc[mt][nt][j];
+        for (int nt = 0; nt < NTILE; ++nt) {
+            const f32x4 v = acc[mt][nt];
+            *(u32x2*)(smem + ((2 * w + (mt >> 1)) * 32 + (mt & 1) * 16 + r16) * PITCH + (nt * 16 + 4 * g) * 2) = u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+        }
     __syncthreads();
     store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, 0, tile, [&](int rr) -> int64_t {
         const int oy = ty * TH + (rr >> 5), ox = tx * TW + (rr & 31);
@@ -1138,7 +1134,7 @@ __global__ __launch_bounds__(256, 2) void pdgrad2_kernel(const IgemmParams p) {
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt)
 #pragma unroll
-                for (int nt = 0; nt < NTILE; ++nt) acc[cls][xt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[xt], bfr[nt], acc[cls][xt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTILE; ++nt) acc[cls][xt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[xt], acc[cls][xt][nt], 0, 0, 0);   // swapped: foreach_acc
         }
     };
 
@@ -1202,10 +1198,10 @@ __global__ __launch_bounds__(256, 2) void pdgrad2_kernel(const IgemmParams p) {
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt)
 #pragma unroll
-            for (int nt = 0; nt < NTILE; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *(bf16_t*)(smem + ((2 * w + (c >> 1)) * 64 + 2 * (xt * 16 + g * 4 + j) + (c & 1)) * PITCH + (nt * 16 + r16) * 2) = (bf16_t)acc[c][xt][nt][j];
+            for (int nt = 0; nt < NTILE; ++nt) {   // MFMA operands swapped (foreach_acc): lane (r16, g) holds cell xt * 16 + r16, channels nt * 16 + 4 g .. + 3
+                const f32x4 v = acc[c][xt][nt];
+                *(u32x2*)(smem + ((2 * w + (c >> 1)) * 64 + 2 * (xt * 16 + r16) + (c & 1)) * PITCH + (nt * 16 + 4 * g) * 2) = u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            }
     __syncthreads();
     store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, 0, tile, [&](int rr) -> int64_t {
         const int oy = ty * 2 * CH + (rr >> 6), ox = tx * 2 * CW + (rr & 63);
