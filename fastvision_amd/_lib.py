@@ -77,6 +77,7 @@ PROTOTYPES = {
     'fva_profile_classes': (_I, [C.c_uint32, _I]),
     'fva_side_stream_fork': (_I, [_P, C.POINTER(C.c_void_p)]),
     'fva_side_stream_join': (_I, [_P]),
+    'fva_side_stream_renew': (_I, []),
     'fva_conv_debug_stamps': (_I, [_P, _I]),
     'fva_conv_patch_kernel': (_I, [_I]),
     'fva_profile_stop': (_I, [_P, _P, _P, _I]),

@@ -103,6 +103,21 @@ extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
 // the library's side stream, or NULL before the first fork (conv_wgrad.hip plans its split-K for the stream it is launched on)
 hipStream_t fva_side_stream_peek() { return g_side; }
 
+// Drop the side stream: the next fork creates a fresh one.  How a HIP stream maps onto the hardware queues is the runtime's choice at
+// creation; on some boxes / processes the low-priority stream lands where it no longer yields to the launch stream (the eager
+// two-stream step then takes 32-35 ms instead of 28.9, profiles/r03_experiments.md).  ops.autotune_wgrad_side_stream() times the step
+// and asks for another stream when the first one loses.  The old stream is drained and left alive (captured graphs may name it).
+extern "C" int fva_side_stream_renew(void) {
+    if (!g_side) return FVA_OK;
+    if (hipStreamSynchronize(g_side) != hipSuccess) return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_renew: synchronize failed");
+    g_side = nullptr;           // events are reused
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess)
+        return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_renew: cannot create the side stream");
+    return FVA_OK;
+}
+
 extern "C" int fva_side_stream_join(void* main_stream) {
     if (!g_side) return FVA_OK;
     hipEvent_t e = side_event();

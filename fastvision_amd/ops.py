@@ -444,7 +444,7 @@ def set_wgrad_side_stream(on):
     return prev
 
 
-def autotune_wgrad_side_stream(step, sync=None, steps=3):
+def autotune_wgrad_side_stream(step, sync=None, steps=3, retries=2):
     """Time ``steps`` calls of ``step()`` with the weight gradients on the launch stream and on the side stream and keep the
     faster setting.  Whether two HIP streams really share the GPU to advantage depends on what else runs (with a host-staged
     gloo all-reduce the side stream LOSES: 108 vs 81 ms per step on a 2-rank test; with one GPU it wins by 4-9 %).  ``sync()``
@@ -473,6 +473,18 @@ def autotune_wgrad_side_stream(step, sync=None, steps=3):
         set_wgrad_side_stream(on)
         step()
         out[name] = round(window(), 3)
+    # A low-priority stream that landed badly among the hardware queues does not yield to the launch stream (32-35 ms per step
+    # instead of 28.9 on some boxes / processes): ask the library for a fresh stream, twice at most, before giving the side stream up.
+    tries = 0
+    while out['on'] > out['off'] and tries < retries:
+        tries += 1
+        join_side_stream()
+        sync()
+        _lib.call('fva_side_stream_renew')
+        step()
+        t = round(window(), 3)
+        out.setdefault('on_first_streams', []).append(out['on'])
+        out['on'] = t
     out['use'] = out['on'] <= out['off']
     set_wgrad_side_stream(out['use'])
     return out

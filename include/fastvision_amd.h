@@ -57,9 +57,12 @@ int fva_profile_classes(uint32_t mask, int32_t stride);
 
 /* A low-priority side stream for work that nothing waits for until the end of the backward pass (the weight gradients).
  * fork: the side stream (returned) waits for everything enqueued on main_stream so far.  join: main_stream waits for
- * everything enqueued on the side stream so far.  Buffers the side stream reads or writes must stay alive until a join. */
+ * everything enqueued on the side stream so far.  Buffers the side stream reads or writes must stay alive until a join.
+ * renew: drain and drop the side stream; the next fork creates a fresh one (how a stream maps onto the hardware queues is decided at its
+ * creation, and a stream that landed badly no longer yields to the launch stream -- ops.autotune_wgrad_side_stream() asks for another). */
 int fva_side_stream_fork(void* main_stream, void** side_stream);
 int fva_side_stream_join(void* main_stream);
+int fva_side_stream_renew(void);
 int32_t fva_profile_stop(int32_t* cls, double* flop, float* ms, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------

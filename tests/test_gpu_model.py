@@ -465,6 +465,20 @@ def test_side_stream_gradient_consumers():
         got = torch.autograd.grad(crit(net(images), tg), params)
         for a, b, c in zip(once, serial, got):
             assert torch.equal(a, b) and torch.equal(a, c)
+        # a fresh side stream (what ops.autotune_wgrad_side_stream asks for when the first one loses) serves the same gradients
+        from fastvision_amd import _lib
+        h0 = ops.fork_side_stream().cuda_stream
+        ops.join_side_stream(force=True)
+        torch.cuda.synchronize()
+        _lib.call('fva_side_stream_renew')
+        h1 = ops.fork_side_stream().cuda_stream
+        ops.join_side_stream(force=True)
+        assert h0 != h1, 'fva_side_stream_renew must hand out a new stream'
+        for p in params:
+            p.grad = None
+        crit(net(images), tg).backward()
+        for p, g in zip(params, once):
+            assert torch.equal(p.grad, g)
 
 
 def _rccl_worker(rank, world, port, out):
