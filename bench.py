@@ -25,6 +25,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Host waits by polling instead of sleeping on an interrupt (read by the HSA runtime when it starts, i.e. before `import torch` touches
+# the device; an explicit setting in the environment wins).  The eager step keeps the host 40 % busy issuing ~900 launches per step and
+# blocks on the full launch queue the rest of the time; four of ~120 eager bench runs on record lost ONE timed step of 180-770 ms to a
+# host that did not come back from such a wait (`step_ms` / `host_issue_ms` of the line show it: DESIGN.md section 5), always on the
+# boxes whose host side is slow (graph capture 2.1-2.9 s instead of 0.55).  Same speed on the good boxes (1093-1096 img/s either way).
+os.environ.setdefault('HSA_ENABLE_INTERRUPT', '0')
+
 import torch  # noqa: E402
 
 METRIC = 'images/sec (640×640, bs=32/GPU) YOLOv3 train step, 1/2/4/8 MI355X'
