@@ -21,8 +21,10 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
 
 // LDS image per buffer: A [64 px][256 ch] and B [64 px][256 ch] as four half images [64 px][128 ch] (256-byte rows), the kernel's layout.
 // MT x NT = 16 x 16 tiles per wave along rows / columns; WAVES = 256 * 256 / (MT * NT * 256).
-template <int MT, int NT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps) {
+// DM: LDS-DMA of the NEXT step's 64 KB image (issued at the start of a step, awaited at its end; 1-KiB instructions of ROWS rows x 1024 / ROWS bytes)
+//   0 none | 1 the same 64 KB of the block every step (cache hits) | 2 a stream of the block's own (no reuse) | 3 a stream shared by 5 blocks
+template <int MT, int NT, int WAVES, int DM, int ROWS>
+__global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, const char* src, long long stride_step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int i = threadIdx.x; i < 2 * 65536 / 4; i += WAVES * 64) ((unsigned*)smem)[i] = 0x3c003c00u + (i & 3);
     __syncthreads();
@@ -55,8 +57,24 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // DMA source of this lane: instruction j (of 64 / WAVES per wave) covers ROWS rows of 1024 / ROWS bytes, rows 512 bytes apart
+    const int blk = DM == 3 ? (int)blockIdx.x / 5 : (int)blockIdx.x;
+    const char* base = src + (DM == 1 ? (long long)blockIdx.x * 65536 : (long long)blk * 65536);
+    constexpr int LPR = 64 / ROWS;                          // lanes per row
+    const int drow = lane / LPR, dcol = (lane % LPR) * 16;
     for (int s = 0; s < steps; ++s) {
         const unsigned boff = (s & 1) * 65536;
+        if (DM != 0) {
+            const char* sb = base + (DM == 1 ? 0ll : (long long)(s + 1) * stride_step);
+#pragma unroll
+            for (int i = 0; i < 64 / WAVES; ++i) {
+                const int j = i * WAVES + w;
+                // the 64 KB image as 64 instructions of ROWS rows x 1024 / ROWS contiguous bytes (the region itself is contiguous)
+                const char* g = sb + (long long)(j * ROWS + drow) * (1024 / ROWS) + dcol;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(smem + ((s + 1) & 1) * 65536 + j * 1024), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                   // two 32-pixel halves of the 64-pixel k-step
             bf16x8 af[MT], bf[NT];
@@ -74,6 +92,7 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DM != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     float t = 0.f;
@@ -84,22 +103,24 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps) {
     if (t == 12345.f) sink[0] = t;
 }
 
-template <int MT, int NT, int WAVES>
-void run(const char* name, float* sink) {
-    hipFuncSetAttribute((const void*)probe<MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+template <int MT, int NT, int WAVES, int DM = 0, int ROWS = 4>
+void run(const char* name, float* sink, const char* src = nullptr) {
+    hipFuncSetAttribute((const void*)probe<MT, NT, WAVES, DM, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const int steps = 2000;
-    probe<MT, NT, WAVES><<<256, WAVES * 64, 131072>>>(sink, 10);
+    const int steps = DM >= 2 ? 60 : 2000;                 // a stream: 60 steps x 256 blocks x 64 KB = 1 GB (one weight-gradient launch)
+    const long long stride = DM == 2 ? 256ll * 65536 : DM == 3 ? 52ll * 65536 : 0;
+    probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072>>>(sink, 10, src, stride);
     hipEventRecord(e0);
-    probe<MT, NT, WAVES><<<256, WAVES * 64, 131072>>>(sink, steps);
+    for (int r = 0; r < (DM >= 2 ? 10 : 1); ++r) probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072>>>(sink, steps, src, stride);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double flop = 256.0 * steps * 2.0 * 256 * 256 * 64;
-    printf("%-44s %8.1f us  %7.1f TFLOP/s  (%.0f ns per 64-pixel k-step)\n", name, ms * 1e3, flop / ms / 1e9, ms * 1e6 / steps);
+    const int reps = DM >= 2 ? 10 : 1;
+    const double flop = 256.0 * steps * reps * 2.0 * 256 * 256 * 64;
+    printf("%-64s %8.1f us  %7.1f TFLOP/s  (%.0f ns per 64-pixel k-step)\n", name, ms * 1e3 / reps, flop / ms / 1e9, ms * 1e6 / steps / reps);
 }
 
 int main() {
@@ -108,5 +129,14 @@ int main() {
     run<8, 4, 8>("8 waves, 128 x 64 wave tiles, serial halves", sink);
     run<8, 8, 4>("4 waves, 128 x 128 wave tiles, serial halves", sink);
     run<4, 8, 8>("8 waves, 64 x 128 wave tiles, serial halves", sink);
+    char* src;
+    hipMalloc(&src, (size_t)(62 * 256 + 8) * 65536);        // ~1 GB
+    hipMemset(src, 0x3c, (size_t)(62 * 256 + 8) * 65536);
+    run<8, 4, 8, 1, 4>("8 waves 128 x 64 + DMA, the same 64 KB every step (4 x 256 B)", sink, src);
+    run<8, 4, 8, 1, 8>("8 waves 128 x 64 + DMA, the same 64 KB every step (8 x 128 B)", sink, src);
+    run<8, 4, 8, 2, 4>("8 waves 128 x 64 + DMA, own stream, no reuse (4 x 256 B)", sink, src);
+    run<8, 4, 8, 3, 4>("8 waves 128 x 64 + DMA, stream shared by 5 blocks (4 x 256 B)", sink, src);
+    run<8, 4, 8, 3, 8>("8 waves 128 x 64 + DMA, stream shared by 5 blocks (8 x 128 B)", sink, src);
+    run<8, 8, 4, 3, 4>("4 waves 128 x 128 + DMA, stream shared by 5 blocks (4 x 256 B)", sink, src);
     return 0;
 }
