@@ -438,6 +438,47 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
 
+#ifndef FVA_WGRAD8_PLAIN
+#define FVA_WGRAD8_PLAIN 0    // 1: EXPERIMENT -- a plain two-buffer loop (one barrier per k-step, the whole next step's LDS-DMA issued at its start)
+#endif
+#if FVA_WGRAD8_PLAIN
+    // tools/probe_wg4.hip runs this loop shape at 1.66 us per k-step with an operand stream shared by five blocks of an XCD
+    uint32_t d1[2], x1[2];
+    {
+        uint32_t d0[2], x0[2];
+        decode(0, d0, x0);
+        stage(2, 0, d0, x0); stage(0, 0, d0, x0); stage(3, 0, d0, x0); stage(1, 0, d0, x0);
+    }
+    decode(1, d1, x1);
+    wait_vmcnt_n<0>();
+    __builtin_amdgcn_s_barrier();
+    stamp(1);
+    auto retire_reads = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        const uint32_t boff = (uint32_t)cur * BUF;
+        if (s + 1 < steps) { stage(2, cur ^ 1, d1, x1); stage(0, cur ^ 1, d1, x1); stage(3, cur ^ 1, d1, x1); stage(1, cur ^ 1, d1, x1); }
+        read_b(boff, K2{}, b0);
+        read_a(boff, K0{});
+        retire_reads();
+        mma(0, 0, b0);
+        read_b(boff, K3{}, b1);
+        retire_reads();
+        mma(0, 1, b1);
+        read_a(boff, K1{});
+        retire_reads();
+        mma(1, 1, b1);
+        decode(s + 2, d1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0, b0);
+        wait_vmcnt_n<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+    stamp(2);
+#else
     // ---- prologue: step 0 complete, three half-tiles of step 1 in flight; offsets of steps 1 and 2 decoded ------------
     uint32_t d1[2], x1[2], d2[2], x2[2];
     {
@@ -495,6 +536,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     stamp(2);
+#endif
 
     // ---- partial tile -> slab[ks][tap][N][C] --------------------------------------------------------------------------
     float* out = p.slab + (int64_t)ks * p.ntaps * p.N * p.C;

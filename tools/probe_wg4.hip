@@ -24,7 +24,7 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
 // DM: LDS-DMA of the NEXT step's 64 KB image (issued at the start of a step, awaited at its end; 1-KiB instructions of ROWS rows x 1024 / ROWS bytes)
 //   0 none | 1 the same 64 KB of the block every step (cache hits) | 2 a stream of the block's own (no reuse) | 3 a stream shared by 5 blocks
 template <int MT, int NT, int WAVES, int DM, int ROWS>
-__global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, const char* src, long long stride_step) {
+__global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, const char* src, long long stride_step, int* progress) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int i = threadIdx.x; i < 2 * 65536 / 4; i += WAVES * 64) ((unsigned*)smem)[i] = 0x3c003c00u + (i & 3);
     __syncthreads();
@@ -58,12 +58,16 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, cons
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // DMA source of this lane: instruction j (of 64 / WAVES per wave) covers ROWS rows of 1024 / ROWS bytes, rows 512 bytes apart
-    const int blk = DM == 3 ? (int)blockIdx.x / 5 : (int)blockIdx.x;
+    // DM 3: the five sharers sit on ONE XCD (workgroups go round-robin over the 8 XCDs), as the kernels' block remap arranges it
+    const int blk = DM == 3 ? ((int)blockIdx.x & 7) * 7 + ((int)blockIdx.x >> 3) / 5 : (int)blockIdx.x;
     const char* base = src + (DM == 1 ? (long long)blockIdx.x * 65536 : (long long)blk * 65536);
     constexpr int LPR = 64 / ROWS;                          // lanes per row
     const int drow = lane / LPR, dcol = (lane % LPR) * 16;
     for (int s = 0; s < steps; ++s) {
         const unsigned boff = (s & 1) * 65536;
+        // progress report: ONE block per XCD, a plain agent-scope store into the XCD's own cache line (256 returning atomics on one line
+        // per step cost 3 us per step: the step's vmcnt(0) waits for them)
+        if (DM == 3 && progress && steps < 0 && threadIdx.x == 0 && (blockIdx.x >> 3) == 0) __hip_atomic_store(progress + (blockIdx.x & 7) * 32, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (DM != 0) {
             const char* sb = base + (DM == 1 ? 0ll : (long long)(s + 1) * stride_step);
 #pragma unroll
@@ -103,21 +107,65 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, cons
     if (t == 12345.f) sink[0] = t;
 }
 
+// L2 prefetcher for DM 3: one wave per XCD walks the XCD's seven shared streams LEAD steps ahead of the slowest progress report with
+// plain loads whose results are dropped (at most 56 in flight), paced by the compute blocks' progress counter; gives up after a while.
+__global__ __launch_bounds__(256) void prefetcher(const char* src, long long stride_step, int steps, int lead, int* progress, unsigned* sink) {
+    const int xcd = blockIdx.x & 7, lane = threadIdx.x & 63, pw = threadIdx.x >> 6;   // four waves per XCD: 114 GB/s per wave is what one wave of line-per-lane loads delivers
+    unsigned acc = 0;
+    const long long t0 = wall_clock64();                  // 100 MHz
+    for (int p = 1; p <= steps; ++p) {
+        int spins = 0;
+        if (lead >= 100) {                                 // open loop: step p not before t0 + (p - 3) * lead * 10 ns
+            while (wall_clock64() - t0 < (long long)(p - 3) * lead && spins < 200000) { __builtin_amdgcn_s_sleep(2); ++spins; }
+        } else {
+            while (__hip_atomic_load(progress + xcd * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lead < p && spins < 200000) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+            }
+        }
+        if (spins >= 200000) break;
+        for (int grp = 0; grp < 7; ++grp) {
+            const char* sb = src + (long long)(xcd * 7 + grp) * 65536 + (long long)p * stride_step + lane * 128;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {                // fire and forget: the result register is never read before the final wait
+                const char* g = sb + (pw * 2 + jj) * 8192;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(acc) : "v"(g));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 0x12345u) sink[0] = acc;
+}
+
 template <int MT, int NT, int WAVES, int DM = 0, int ROWS = 4>
-void run(const char* name, float* sink, const char* src = nullptr) {
+void run(const char* name, float* sink, const char* src = nullptr, int lead = -1) {
     hipFuncSetAttribute((const void*)probe<MT, NT, WAVES, DM, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int steps = DM >= 2 ? 60 : 2000;                 // a stream: 60 steps x 256 blocks x 64 KB = 1 GB (one weight-gradient launch)
-    const long long stride = DM == 2 ? 256ll * 65536 : DM == 3 ? 52ll * 65536 : 0;
-    probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072>>>(sink, 10, src, stride);
-    hipEventRecord(e0);
-    for (int r = 0; r < (DM >= 2 ? 10 : 1); ++r) probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072>>>(sink, steps, src, stride);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
+    const long long stride = DM == 2 ? 256ll * 65536 : DM == 3 ? 56ll * 65536 : 0;
+    static int* progress = nullptr;
+    static hipStream_t s1 = nullptr, s2 = nullptr;
+    if (!progress) { hipMalloc(&progress, 1024); hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking); }
+    probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072>>>(sink, 10, src, stride, nullptr);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    for (int r = 0; r < (DM >= 2 ? 10 : 1); ++r) {
+        if (lead >= 0) {
+            hipMemsetAsync(progress, 0, 1024, 0);
+            hipStreamSynchronize(0);
+            prefetcher<<<8, 256, 0, s2>>>(src, stride, steps, lead, progress, (unsigned*)sink);
+        }
+        hipEventRecord(e0, s1);
+        probe<MT, NT, WAVES, DM, ROWS><<<256, WAVES * 64, 131072, s1>>>(sink, steps, src, stride, lead >= 0 ? progress : nullptr);
+        hipEventRecord(e1, s1);
+        hipEventSynchronize(e1);
+        float t;
+        hipEventElapsedTime(&t, e0, e1);
+        ms += t;
+        if (lead >= 0) hipStreamSynchronize(s2);
+    }
     const int reps = DM >= 2 ? 10 : 1;
     const double flop = 256.0 * steps * reps * 2.0 * 256 * 256 * 64;
     printf("%-64s %8.1f us  %7.1f TFLOP/s  (%.0f ns per 64-pixel k-step)\n", name, ms * 1e3 / reps, flop / ms / 1e9, ms * 1e6 / steps / reps);
@@ -138,5 +186,31 @@ int main() {
     run<8, 4, 8, 3, 4>("8 waves 128 x 64 + DMA, stream shared by 5 blocks (4 x 256 B)", sink, src);
     run<8, 4, 8, 3, 8>("8 waves 128 x 64 + DMA, stream shared by 5 blocks (8 x 128 B)", sink, src);
     run<8, 8, 4, 3, 4>("4 waves 128 x 128 + DMA, stream shared by 5 blocks (4 x 256 B)", sink, src);
+    run<8, 4, 8, 3, 4>("... + L2 prefetch wave per XCD, open loop 1.6 us per step", sink, src, 160);
+    {   // do the two kernels overlap at all?  wall-clock of each alone and of both (compute launched FIRST here)
+        hipStream_t a, b;
+        hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+        hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+        int* prog;
+        hipMalloc(&prog, 1024);
+        hipMemset(prog, 0, 1024);
+        auto wall = [&](int which) {
+            hipDeviceSynchronize();
+            hipEvent_t e0, e1, e2, e3;
+            hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3);
+            const long long stride = 56ll * 65536;
+            hipEventRecord(e0, a);
+            if (which & 1) probe<8, 4, 8, 3, 4><<<256, 512, 131072, a>>>(sink, 60, src, stride, nullptr);
+            hipEventRecord(e1, a);
+            hipEventRecord(e2, b);
+            if (which & 2) prefetcher<<<8, 256, 0, b>>>(src, stride, 60, 160, prog, (unsigned*)sink);
+            hipEventRecord(e3, b);
+            hipDeviceSynchronize();
+            float ta, tb, tab;
+            hipEventElapsedTime(&ta, e0, e1); hipEventElapsedTime(&tb, e2, e3); hipEventElapsedTime(&tab, e0, e3);
+            printf("which %d: compute %.1f us, prefetcher %.1f us, first start to last end %.1f us\n", which, ta * 1e3, tb * 1e3, tab * 1e3);
+        };
+        wall(1); wall(2); wall(3); wall(3);
+    }
     return 0;
 }
