@@ -4,6 +4,9 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/probe_wg4.hip -o tools/probe_wg4 && tools/probe_wg4
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#ifndef PF_ATOMIC
+#define PF_ATOMIC 0
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, cons
 __global__ __launch_bounds__(256) void prefetcher(const char* src, long long stride_step, int steps, int lead, int* progress, unsigned* sink) {
     const int xcd = blockIdx.x & 7, lane = threadIdx.x & 63, pw = threadIdx.x >> 6;   // four waves per XCD: 114 GB/s per wave is what one wave of line-per-lane loads delivers
     unsigned acc = 0;
+    const unsigned zero = 0;
     const long long t0 = wall_clock64();                  // 100 MHz
     for (int p = 1; p <= steps; ++p) {
         int spins = 0;
@@ -129,7 +133,11 @@ __global__ __launch_bounds__(256) void prefetcher(const char* src, long long str
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {                // fire and forget: the result register is never read before the final wait
                 const char* g = sb + (pw * 2 + jj) * 8192;
+#if PF_ATOMIC
+                asm volatile("global_atomic_or %0, %1, off" :: "v"(g), "v"(zero) : "memory");   // executes at L2, returns nothing to the CU
+#else
                 asm volatile("global_load_dword %0, %1, off" : "+v"(acc) : "v"(g));
+#endif
             }
         }
     }
