@@ -110,6 +110,73 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* sink, int steps, cons
     if (t == 12345.f) sink[0] = t;
 }
 
+// The same work as probe<8, 4, 8, 3> with 32-pixel k-steps and a ring of five 32-KB LDS buffers (160 KB): the DMA of step s + 4 is issued
+// at step s, so that four steps (two 64-pixel steps) lie between issue and use instead of one.  vmcnt(12) at the end of a step leaves the
+// three youngest steps' DMA (4 instructions per wave each) in flight.
+__global__ __launch_bounds__(512) void probe_ring(float* sink, int steps32, const char* src, long long stride_step) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 5 * 32768 / 4; i += 512) ((unsigned*)smem)[i] = 0x3c003c00u + (i & 3);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 2, wc = w & 3;
+    const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // buffer = A [32 px][256 ch] as two half images [32 px][128 ch] (8 KB each), then B likewise
+    unsigned ra[2][8], rb[2][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = 8 * g + 4 * hh + q;
+        const int fr = (q << 2) | ((2 * g + hh) & 3);
+        const int rbase = row * 256 + 8 * (pp & 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int tile = wr * 8 + t; ra[hh][t] = lds0 + (tile >> 3) * 8192 + rbase + ((((tile & 7) * 2 + (pp >> 1)) ^ fr) << 4); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int tile = wc * 4 + t; rb[hh][t] = lds0 + 16384 + (tile >> 3) * 8192 + rbase + ((((tile & 7) * 2 + (pp >> 1)) ^ fr) << 4); }
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int blk = ((int)blockIdx.x & 7) * 7 + ((int)blockIdx.x >> 3) / 5;
+    const char* base = src + (long long)blk * 65536 + lane * 16;
+    auto issue = [&](int step) {                          // 32 KB = 32 instructions, 4 per wave; two 32-pixel steps share a 64-KB region
+        const char* sb = base + (long long)(step >> 1) * stride_step + (step & 1) * 32768;
+        char* dst = smem + (step % 5) * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = i * 8 + w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + j * 1024), (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+    for (int s = 1; s <= 4; ++s) issue(s + 1);            // steps 2..5 in flight (step 0 / 1 use the initial LDS contents)
+    for (int s = 0; s < steps32; ++s) {
+        const unsigned boff = (s % 5) * 32768;
+        bf16x8 af[8], bf[4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) af[t] = cat8(tr_read<0>(ra[0][t] + boff), tr_read<0>(ra[1][t] + boff));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = cat8(tr_read<0>(rb[0][t] + boff), tr_read<0>(rb[1][t] + boff));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // step s + 1 has landed (steps s + 2 .. s + 4 may fly)
+        __builtin_amdgcn_s_barrier();
+        if (s + 5 < steps32 + 5) issue(s + 5);             // into the buffer every wave has just finished reading
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][3];
+    if (t == 12345.f) sink[0] = t;
+}
+
 // L2 prefetcher for DM 3: one wave per XCD walks the XCD's seven shared streams LEAD steps ahead of the slowest progress report with
 // plain loads whose results are dropped (at most 56 in flight), paced by the compute blocks' progress counter; gives up after a while.
 __global__ __launch_bounds__(256) void prefetcher(const char* src, long long stride_step, int steps, int lead, int* progress, unsigned* sink) {
@@ -195,7 +262,25 @@ int main() {
     run<8, 4, 8, 3, 8>("8 waves 128 x 64 + DMA, stream shared by 5 blocks (8 x 128 B)", sink, src);
     run<8, 8, 4, 3, 4>("4 waves 128 x 128 + DMA, stream shared by 5 blocks (4 x 256 B)", sink, src);
     run<8, 4, 8, 3, 4>("... + L2 prefetch wave per XCD, open loop 1.6 us per step", sink, src, 160);
-    {   // do the two kernels overlap at all?  wall-clock of each alone and of both (compute launched FIRST here)
+    {
+        hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        probe_ring<<<256, 512, 163840>>>(sink, 20, src, 56ll * 65536);
+        hipDeviceSynchronize();
+        printf("ring launch: %s\n", hipGetErrorString(hipGetLastError()));
+        float ms = 0.f;
+        for (int r = 0; r < 10; ++r) {
+            hipEventRecord(e0);
+            probe_ring<<<256, 512, 163840>>>(sink, 120, src, 56ll * 65536);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float t; hipEventElapsedTime(&t, e0, e1); ms += t;
+        }
+        printf("%-64s %8.1f us  %7.1f TFLOP/s  (%.0f ns per 64 pixels)\n", "8 waves 128 x 64, 32-pixel steps, ring of five 32-KB buffers, shared by 5", ms * 100,
+               256.0 * 60 * 10 * 2.0 * 256 * 256 * 64 / ms / 1e9, ms * 1e6 / 60 / 10);
+    }
+    if (0) {   // do the two kernels overlap at all?  wall-clock of each alone and of both (compute launched FIRST here)
         hipStream_t a, b;
         hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
         hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
