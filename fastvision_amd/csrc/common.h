@@ -88,6 +88,27 @@ __device__ __forceinline__ float silu_grad(float u) {
     return s * (1.f + u * (1.f - s));
 }
 
+// ---- second pass of the BatchNorm + SiLU backward, per element (bn_act.hip's apply kernels and the apply "rider" of the weight-gradient
+// kernels share these, so that a pass produces the same bits wherever it runs):  dY = a * dU + k1 * y + k2,  dU = dz * SiLU'(y * a + shift),
+// a = gamma * rstd (= the forward scale), k1 = coefB * rstd, k2 = coefC - k1 * mean  (coef = fva_bn_bwd_finalize's [3][C] table).
+struct BnBwdK {
+    float a, sh, k1, k2;
+};
+__device__ __forceinline__ BnBwdK bn_bwd_pack_coef(float a, float shift, float mean, float rstd, float coef_b, float coef_c) {
+    BnBwdK k;
+    k.a = a;
+    k.sh = shift;
+    k.k1 = coef_b * rstd;
+    k.k2 = __builtin_fmaf(-k.k1, mean, coef_c);
+    return k;
+}
+// sc: the forward scale (scale[c]); a: coef[c].  Both are gamma * rstd, computed by fva_bn_finalize and fva_bn_bwd_finalize from the same
+// two floats, hence the same bits; the riders keep one copy (BnBwdK::a) and pass it for both.
+__device__ __forceinline__ float bn_bwd_apply_elem(float dz, float y, float sc, float sh, float a, float k1, float k2) {
+    const float du = dz * silu_grad(__builtin_fmaf(y, sc, sh));
+    return __builtin_fmaf(a, du, __builtin_fmaf(k1, y, k2));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
