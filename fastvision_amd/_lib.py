@@ -57,12 +57,6 @@ class BnBwdFin(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('counters', 'group_sums', 'gamma', 'dgamma', 'dbeta', 'coef')] + [('accumulate', C.c_int32)]
 
 
-class BnBwdJob(C.Structure):
-    """fva_bn_bwd_job: a BatchNorm-backward apply pass, or a piece of one (chunks of the padded output buffer)."""
-    _fields_ = [(n, C.c_void_p) for n in ('dz', 'y', 'scale', 'shift', 'save_mean', 'save_rstd', 'coef', 'dy')] + \
-               [(n, C.c_int32) for n in ('dy_pad', 'B', 'H', 'W', 'C')] + [('chunk_begin', C.c_int64), ('chunk_end', C.c_int64)]
-
-
 class ColourJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('h', 'w', 'clahe', 'hsv', 'blur')] + [('perm', C.c_int32 * 3)]
 
@@ -106,9 +100,6 @@ PROTOTYPES = {
     'fva_conv_dgrad_stat_rows': (_I, [_D]),
     'fva_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _L, _P]),
     'fva_conv_wgrad_workspace': (_L, [_D]),
-    'fva_conv_wgrad_ride_capacity': (_L, [_D, _I]),
-    'fva_conv_wgrad_ride': (_I, [_D, _P, _P, _P, _I, _P, _L, C.POINTER(BnBwdJob), _P]),
-    'fva_bn_silu_bwd_apply_range': (_I, [_I, C.POINTER(BnBwdJob), _P]),
     'fva_stem_fwd': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     'fva_stem_fwd_workspace': (_L, [_I, _I, _I, _I]),
     'fva_stem_stat_blocks': (_I, [_I, _I, _I, _I]),
@@ -172,7 +163,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_conv_patch_kernel', 'fva_bn_ticket_groups', 'fva_bn_ticket_counters', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace', 'fva_conv_wgrad_ride_capacity',
+UNCHECKED = {'fva_conv_patch_kernel', 'fva_bn_ticket_groups', 'fva_bn_ticket_counters', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

@@ -371,46 +371,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// The same pass over a RANGE of 16-byte chunks of the padded output buffer (fva_bn_bwd_job): the pieces of a pass that no
-// weight-gradient launch carried (conv_wgrad.hip, the apply rider).  A thread keeps its channel chunk (cpp divides 256).
-__global__ __launch_bounds__(256) void bn_bwd_apply_range_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
-                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 const float* __restrict__ coef, bf16_t* __restrict__ dy, const HaloIdx h,
-                                                                 uint32_t begin, uint32_t end) {
-    constexpr int U = 2;
-    const int cc = (begin + threadIdx.x) & (h.cpp - 1);
-    float sc[8], sh[8], ka[8], k1[8], k2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = cc * 8 + e;
-        const BnBwdK k = bn_bwd_pack_coef(coef[c], shift[c], mean[c], rstd[c], coef[h.C + c], coef[2 * h.C + c]);
-        sc[e] = scale[c]; sh[e] = k.sh; ka[e] = k.a; k1[e] = k.k1; k2[e] = k.k2;
-    }
-    const uint32_t stride = gridDim.x * 256u * U;
-    for (uint32_t i0 = begin + blockIdx.x * 256u * U + threadIdx.x; i0 < end; i0 += stride) {
-        Vec16<bf16_t> g[U], v[U];
-        bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = i0 + u * 256u;
-            int b, yy, xx, c2;
-            in[u] = halo_decode(h, i < end ? i : begin, b, yy, xx, c2) && i < end;
-            const int64_t off = in[u] ? (((int64_t)b * h.H + yy) * h.W + xx) * h.C + cc * 8 : 0;
-            g[u] = ld_last<bf16_t>(dz + off);
-            v[u] = ld_last<bf16_t>(y + off);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = i0 + u * 256u;
-            Vec16<bf16_t> out;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) out.set(e, in[u] ? bn_bwd_apply_elem(g[u].get(e), v[u].get(e), sc[e], sh[e], ka[e], k1[e], k2[e]) : 0.f);
-            if (i < end) *(Vec16<bf16_t>*)(dy + (int64_t)i * 8) = out;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // nearest x2 upsample + channel concat into a halo buffer (pad 1)
 template <typename T>
@@ -678,28 +638,6 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), cap_lds, s, (const float*)dz, (const float*)y,
                            scale, shift, save_mean, save_rstd, coef, (float*)dy, h, nrows);
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
-    return FVA_OK;
-}
-
-int fva_bn_silu_bwd_apply_range(int dtype, const fva_bn_bwd_job* j, void* stream) {
-    if (!j) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: null job");
-    if (dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: bf16 only");
-    int rc = check_chan(dtype, j->C, "fva_bn_silu_bwd_apply_range");
-    if (rc) return rc;
-    if (!j->dz || !j->y || !j->scale || !j->shift || !j->save_mean || !j->save_rstd || !j->coef || !j->dy)
-        return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: null pointer");
-    const HaloIdx h = make_halo(j->B, j->H, j->W, j->C, j->dy_pad, 8);
-    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: tensor too large");
-    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: C=%d must be a power of two (<= 256 chunks)", j->C);
-    if (j->chunk_begin < 0 || j->chunk_end > h.total || j->chunk_begin > j->chunk_end || j->chunk_begin % h.cpp)
-        return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_range: bad chunk range [%lld, %lld) of %lld", (long long)j->chunk_begin, (long long)j->chunk_end, (long long)h.total);
-    if (j->chunk_begin == j->chunk_end) return FVA_OK;
-    const int64_t n = j->chunk_end - j->chunk_begin;
-    int grid = (int)((n + 511) / 512);
-    if (grid > 256 * 8) grid = 256 * 8;
-    hipLaunchKernelGGL(bn_bwd_apply_range_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)j->dz, (const bf16_t*)j->y, j->scale,
-                       j->shift, j->save_mean, j->save_rstd, j->coef, (bf16_t*)j->dy, h, (uint32_t)j->chunk_begin, (uint32_t)j->chunk_end);
-    FVA_LAUNCH_CHECK("bn_bwd_apply_range_kernel");
     return FVA_OK;
 }
 

@@ -58,25 +58,6 @@ struct WgradParams {
     int stamp_rows;    // capacity of the caller's buffer in blocks
 };
 
-// ---- the apply rider ------------------------------------------------------------------------------------------------------------
-// The weight gradient is the one MFMA-bound piece of the backward pass that nothing waits for; the second BatchNorm-backward pass
-// (dz, y -> dY, 6 bytes per element, HBM-bound, on the dependency chain of the NEXT layer down) used to be a launch of its own
-// between two MFMA-bound ones.  A hosting weight-gradient launch carries a piece of such a pass of ANOTHER layer (fva_bn_bwd_job):
-// every thread moves one 16-byte chunk per k-step -- dz and y by LDS-DMA into a wave-private scratch slot (no register is held
-// while the data is in flight), one k-step later eight elements of arithmetic between the matrix instructions and one 16-byte
-// store.  In vmcnt terms the rider's three operations sit behind the k-step's last staging instruction, so the k loop's own
-// `vmcnt(6)` of the NEXT k-step covers them (in-order counter): the rider adds no wait of its own.
-struct RideParams {
-    const char* dz;
-    const char* y;
-    char* dy;
-    const float *scale, *shift, *mean, *rstd, *coef;
-    uint32_t begin, end;   // chunk range of the padded output buffer
-    int C, cshift;         // channels, log2(chunks per pixel)
-    int H, W, pad, Wp, HWp;
-    FastDiv div_wp, div_img;
-};
-
 // ds_read_b64_tr_b16 as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever an LDS-DMA
 // is in flight, which would serialise the next tile's DMA with this tile's MFMAs.  The asm form is invisible to
 // that bookkeeping; its completion is awaited by hand (`s_waitcnt lgkmcnt(0)` + sched_barrier) before the MFMAs.
@@ -310,10 +291,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 //   of the four wave columns (with Cin = 128 a column tile holds two taps side by side).
 //   q0: read B-h0, A-h0 | stage A-h1(s+1)   q1: read B-h1 | stage B-h0(s+2)   q2: read A-h1 | stage A-h0(s+2)
 //   q3: decode the pixels of step s+3 | stage B-h1(s+2), vmcnt(6).  RAW / WAR as in igemm8_kernel.
-template <bool RIDE>
-__global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p, const RideParams rp) {
+__global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     constexpr int BKP = 64, OP = BKP * 256, BUF = 4 * OP;
-    constexpr int RIDE_TAB = 2 * BUF, RIDE_SCR = 2 * BUF + 16384;   // LDS behind the two staging buffers: [C][4] coefficients, [8 waves][dz | y][64 lanes] x 16 B
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 2, wc = w & 3;
@@ -328,7 +307,6 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p, const 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int lblk = logical;
     const int per_ks = p.ngroups * p.ntn * p.ntc;
     const int ks = logical / per_ks;
     logical -= ks * per_ks;
@@ -339,64 +317,6 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p, const 
     const int mbeg = ks * p.mchunk;
     const int mend = (mbeg + p.mchunk < p.M) ? mbeg + p.mchunk : p.M;
     const int steps = p.mchunk / BKP;
-
-    // ---- the rider: coefficient table to LDS before the first LDS-DMA is in flight (hipcc drains vmcnt in front of any LDS access
-    // it can see once one is); thread t handles chunk  begin + (lblk * steps + j) * 512 + t  in k-step j ------------------------------
-    uint32_t r_idx = 0, r_pend = 0, r_tab = 0, r_scr = 0;       // next chunk; pending chunk (byte offset | 1 interior | 2 valid); LDS addresses
-    if constexpr (RIDE) {
-        f32x4* tab = (f32x4*)(smem + RIDE_TAB);
-        for (int c = tid; c < rp.C; c += 512) {
-            const BnBwdK k = bn_bwd_pack_coef(rp.coef[c], rp.shift[c], rp.mean[c], rp.rstd[c], rp.coef[rp.C + c], rp.coef[2 * rp.C + c]);
-            tab[c] = f32x4{rp.scale[c], k.sh, k.k1, k.k2};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the raw s_barrier of the prologue does not wait for LDS stores
-        r_idx = rp.begin + (uint32_t)lblk * (uint32_t)steps * 512u + (uint32_t)tid;
-        r_tab = (uint32_t)(size_t)LDS_PTR(smem + RIDE_TAB) + ((r_idx & ((1u << rp.cshift) - 1u)) << 7);   // 8 channels x 16 B
-        r_scr = (uint32_t)(size_t)LDS_PTR(smem + RIDE_SCR) + (uint32_t)w * 2048u + (uint32_t)lane * 16u;
-    }
-    // issue: the chunk's dz and y pieces -> this wave's scratch slots (a border or out-of-range chunk reads element 0 and is ignored)
-    auto ride_issue = [&]() {
-        const uint32_t idx = r_idx;
-        const uint32_t pix = idx >> rp.cshift, cc = idx & ((1u << rp.cshift) - 1u);
-        const uint32_t b = fd_div(pix, rp.div_img);
-        const uint32_t rem = pix - b * (uint32_t)rp.HWp;
-        const uint32_t yp = fd_div(rem, rp.div_wp);
-        const uint32_t xp = rem - yp * (uint32_t)rp.Wp;
-        const uint32_t yy = yp - (uint32_t)rp.pad, xx = xp - (uint32_t)rp.pad;
-        const bool valid = idx < rp.end;
-        const bool inside = valid && yy < (uint32_t)rp.H && xx < (uint32_t)rp.W;
-        const uint32_t src = inside ? (((b * (uint32_t)rp.H + yy) * (uint32_t)rp.W + xx) * (uint32_t)rp.C + cc * 8u) * 2u : 0u;
-        char* scr = smem + RIDE_SCR + w * 2048;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(rp.dz + src), LDS_PTR(scr), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(rp.y + src), LDS_PTR(scr + 1024), 16, 0, 0);
-        r_pend = (idx << 4) | (inside ? 1u : 0u) | (valid ? 2u : 0u);
-        r_idx = idx + 512u;
-    };
-    // consume: the pending chunk's data has landed (the k loop's vmcnt covers the rider's DMA of the previous k-step)
-    auto ride_consume = [&]() {
-        u32x4 g, v;
-        f32x4 k[8];
-        asm volatile("ds_read_b128 %0, %1" : "=v"(g) : "v"(r_scr));
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v) : "v"(r_scr));
-#define FVA_RIDE_K(E) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(k[E]) : "v"(r_tab), "n"(E * 16));
-        FVA_RIDE_K(0) FVA_RIDE_K(1) FVA_RIDE_K(2) FVA_RIDE_K(3) FVA_RIDE_K(4) FVA_RIDE_K(5) FVA_RIDE_K(6) FVA_RIDE_K(7)
-#undef FVA_RIDE_K
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const bool inside = r_pend & 1u;
-        u32x4 o;
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-            const float g0 = __builtin_bit_cast(float, g[e2] << 16), g1 = __builtin_bit_cast(float, g[e2] & 0xffff0000u);
-            const float y0 = __builtin_bit_cast(float, v[e2] << 16), y1 = __builtin_bit_cast(float, v[e2] & 0xffff0000u);
-            const f32x4 ka = k[2 * e2], kb = k[2 * e2 + 1];
-            const float o0 = bn_bwd_apply_elem(g0, y0, ka[0], ka[1], ka[0], ka[2], ka[3]);
-            const float o1 = bn_bwd_apply_elem(g1, y1, kb[0], kb[1], kb[0], kb[2], kb[3]);
-            o[e2] = inside ? cvt_pk_bf16(o0, o1) : 0u;
-        }
-        if (r_pend & 2u) *(u32x4*)(rp.dy + (r_pend & ~15u)) = o;
-    };
-    (void)r_tab; (void)r_scr; (void)r_pend;
 
     // ---- LDS-DMA source mapping: one instruction = 4 pixel rows x 256 B of a half-tile image ------------------------
     const int lrow = lane >> 4;
@@ -612,19 +532,9 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p, const 
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 0, b0);
-        if constexpr (RIDE) {           // every fragment register is dead here; the matrix instructions just issued run beside this
-            __builtin_amdgcn_sched_barrier(0);
-            if (s > 0) ride_consume();
-            ride_issue();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    if constexpr (RIDE) {
-        wait_vmcnt_n<0>();
-        ride_consume();
-    }
     stamp(2);
 #endif
 
@@ -1170,47 +1080,8 @@ int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d) {
     return (int64_t)ks * pl.ntaps * d->Cout * d->Cin * 4;
 }
 
-// chunks a hosting launch carries: one per thread and k-step (wgrad8_kernel<true>)
-static int64_t ride_capacity(const fva_conv_desc* d, int job_channels) {
-    static const bool on = [] { const char* e = getenv("FVA_RIDE"); return !e || atoi(e) != 0; }();
-    if (!on || !d || !use_wgrad8(d)) return 0;
-    const int cpp = job_channels / 8;
-    if (job_channels % 8 || job_channels > 1024 || cpp < 1 || (cpp & (cpp - 1))) return 0;
-    WgradPlan pl;
-    plan_wgrad(d, pl, false);
-    return (int64_t)pl.ksplit * pl.ngroups * pl.ntn * pl.ntc * (pl.mchunk / 64) * 512;
-}
-
-static int conv_wgrad_impl(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
-                           int64_t workspace_bytes, const fva_bn_bwd_job* job, void* stream);
-
-int64_t fva_conv_wgrad_ride_capacity(const fva_conv_desc* d, int32_t job_channels) { return ride_capacity(d, job_channels); }
-
 int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
                    int64_t workspace_bytes, void* stream) {
-    return conv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, nullptr, stream);
-}
-
-int fva_conv_wgrad_ride(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
-                        int64_t workspace_bytes, const fva_bn_bwd_job* job, void* stream) {
-    if (!job) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: null job");
-    if (!job->dz || !job->y || !job->scale || !job->shift || !job->save_mean || !job->save_rstd || !job->coef || !job->dy)
-        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: null pointer in the job");
-    const int64_t cap = ride_capacity(d, job->C);
-    const int cpp = job->C / 8;
-    const int64_t total = (int64_t)job->B * (job->H + 2 * job->dy_pad) * (job->W + 2 * job->dy_pad) * cpp;
-    if (cap <= 0) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: this layer's weight-gradient kernel does not host (or C=%d is not hostable)", job->C);
-    if (job->chunk_begin < 0 || job->chunk_begin > job->chunk_end || job->chunk_end > total || job->chunk_begin % cpp)
-        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: bad chunk range [%lld, %lld) of %lld", (long long)job->chunk_begin, (long long)job->chunk_end, (long long)total);
-    if (job->chunk_end - job->chunk_begin > cap)
-        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: %lld chunks exceed the launch's capacity %lld", (long long)(job->chunk_end - job->chunk_begin), (long long)cap);
-    if (total * 16 >= (1ll << 32) || (int64_t)job->B * job->H * job->W * job->C * 2 >= (1ll << 32))
-        return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad_ride: job tensor larger than 4 GiB (32-bit byte offsets)");
-    return conv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, job, stream);
-}
-
-static int conv_wgrad_impl(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
-                           int64_t workspace_bytes, const fva_bn_bwd_job* job, void* stream) {
     if (!d || !x || !dy || !dw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: null pointer");
     if (d->dtype != FVA_F32 && d->dtype != FVA_BF16) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: bad dtype");
     if (!((d->ksize == 1 && d->stride == 1) || (d->ksize == 3 && (d->stride == 1 || d->stride == 2))))
@@ -1224,7 +1095,7 @@ static int conv_wgrad_impl(const fva_conv_desc* d, const void* x, const void* dy
         (int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cout * esz >= (1ll << 32))
         return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
-    const bool beside = !job && stream != nullptr && (hipStream_t)stream == fva_side_stream_peek();   // a hosting launch is planned for the whole chip
+    const bool beside = stream != nullptr && (hipStream_t)stream == fva_side_stream_peek();
     plan_wgrad(d, pl, beside);
     FvaProfileSpan span(2 | (d->ksize << 8), 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     if (use_pwgrad(d)) {
@@ -1289,29 +1160,12 @@ static int conv_wgrad_impl(const fva_conv_desc* d, const void* x, const void* dy
     if (pl.tile == 256) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)wgrad8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * 256);
-            (void)hipFuncSetAttribute((const void*)wgrad8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * 256 + 32768);
+            (void)hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * 256);
             attr_done = true;
         }
         p.stamps = fva_debug_stamps_ptr();
         p.stamp_rows = fva_debug_stamps_rows();
-        RideParams rp = RideParams();
-        if (job) {
-            const int cpp = job->C / 8;
-            rp.dz = (const char*)job->dz; rp.y = (const char*)job->y; rp.dy = (char*)job->dy;
-            rp.scale = job->scale; rp.shift = job->shift; rp.mean = job->save_mean; rp.rstd = job->save_rstd; rp.coef = job->coef;
-            rp.begin = (uint32_t)job->chunk_begin; rp.end = (uint32_t)job->chunk_end;
-            rp.C = job->C;
-            rp.cshift = 0;
-            while ((1 << rp.cshift) < cpp) ++rp.cshift;
-            rp.H = job->H; rp.W = job->W; rp.pad = job->dy_pad;
-            rp.Wp = job->W + 2 * job->dy_pad;
-            rp.HWp = (job->H + 2 * job->dy_pad) * rp.Wp;
-            rp.div_wp = make_fastdiv(rp.Wp);
-            rp.div_img = make_fastdiv(rp.HWp);
-            hipLaunchKernelGGL(wgrad8_kernel<true>, dim3(grid), dim3(512), 2 * 4 * 64 * 256 + 32768, s, p, rp);
-        } else
-            hipLaunchKernelGGL(wgrad8_kernel<false>, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p, rp);
+        hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
     } else if (d->dtype == FVA_BF16 && d->Cout <= 64 && wgrad_thin_enabled())
         hipLaunchKernelGGL((wgrad_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, p);
     else if (d->dtype == FVA_BF16)

@@ -273,26 +273,6 @@ int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, i
 int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
                           const float* save_mean, const float* save_rstd, const float* coef, void* dy, int dy_pad,
                           int B, int H, int W, int C, void* stream);
-/* The same pass as a JOB that can be cut into pieces: the padded output buffer [B][H+2p][W+2p][C] seen as a row of 16-byte
- * chunks (8 bf16 channels of one pixel; border pixels are written as zeros), of which a call produces [chunk_begin, chunk_end).
- * fva_bn_silu_bwd_apply_range runs a piece as its own launch.  fva_conv_wgrad_ride runs a piece INSIDE a weight-gradient launch
- * of another layer: the MFMA waves of that launch also stream the piece (LDS-DMA in, a few VALU instructions between their
- * matrix instructions, 16-byte stores out), so that this HBM-bound pass costs the backward chain no launch of its own -- the
- * weight gradient has no consumer before the optimizer and is the only MFMA-bound work of the backward pass that is off the
- * dependency chain (autograd's backward of classfication/models/darknet53.py:22-44).  Every piece writes the same bits
- * wherever it runs.  bf16 only; C / 8 a power of two, C <= 1024; chunk_begin a multiple of C / 8.
- * fva_conv_wgrad_ride_capacity: chunks one launch of this layer's weight gradient carries (0: its kernel does not host). */
-typedef struct {
-    const void *dz, *y;                                        /* dense [B*H*W][C] */
-    const float *scale, *shift, *save_mean, *save_rstd, *coef; /* as fva_bn_silu_bwd_apply */
-    void* dy;                                                  /* halo buffer, border dy_pad */
-    int32_t dy_pad, B, H, W, C;
-    int64_t chunk_begin, chunk_end;
-} fva_bn_bwd_job;
-int fva_bn_silu_bwd_apply_range(int dtype, const fva_bn_bwd_job* job, void* stream);
-int64_t fva_conv_wgrad_ride_capacity(const fva_conv_desc* d, int32_t job_channels);
-int fva_conv_wgrad_ride(const fva_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate, void* workspace,
-                        int64_t workspace_bytes, const fva_bn_bwd_job* job, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FPN glue and layout conversion.  Replaces nn.Upsample(scale_factor=2,'nearest') + torch.cat
