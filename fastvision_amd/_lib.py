@@ -7,7 +7,15 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('FVA_LIB_PATH') or os.path.join(HERE, 'csrc', 'libfastvision_amd.so')   # FVA_LIB_PATH: another in-tree build of the same sources (kernel A/Bs)
+LIB_PATH = os.path.join(HERE, 'csrc', 'libfastvision_amd.so')
+if os.environ.get('FVA_LIB_PATH'):
+    # kernel A/Bs against another build of the same sources: an explicit opt-in, announced (it replaces the whole library)
+    if os.environ.get('FVA_EXPERIMENTS') == '1':
+        LIB_PATH = os.environ['FVA_LIB_PATH']
+        import sys
+        print(f'fastvision_amd: EXPERIMENT -- loading {LIB_PATH} instead of the in-tree library (FVA_LIB_PATH)', file=sys.stderr)
+    else:
+        raise RuntimeError('fastvision_amd: FVA_LIB_PATH is set but FVA_EXPERIMENTS=1 is not -- refusing to load another library silently')
 
 F32, BF16 = 0, 1
 
@@ -46,17 +54,6 @@ class BnBwdFuse(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('y', 'scale', 'shift', 'mean', 'rstd', 'partial')]
 
 
-class BnFwdFin(C.Structure):
-    """fva_bn_fwd_fin: BatchNorm finalisation inside the convolution launch (csrc/bn_ticket.h)."""
-    _fields_ = [(n, C.c_void_p) for n in ('counters', 'group_sums', 'gamma', 'beta', 'running_mean', 'running_var', 'num_batches_tracked')] + \
-               [('momentum', C.c_float), ('eps', C.c_float)] + [(n, C.c_void_p) for n in ('save_mean', 'save_rstd', 'scale', 'shift')]
-
-
-class BnBwdFin(C.Structure):
-    """fva_bn_bwd_fin"""
-    _fields_ = [(n, C.c_void_p) for n in ('counters', 'group_sums', 'gamma', 'dgamma', 'dbeta', 'coef')] + [('accumulate', C.c_int32)]
-
-
 class ColourJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('h', 'w', 'clahe', 'hsv', 'blur')] + [('perm', C.c_int32 * 3)]
 
@@ -85,14 +82,8 @@ PROTOTYPES = {
     'fva_conv_packed_elems': (_L, [_D, _I]),
     'fva_conv_pack_weights_multi': (_I, [_P, _I, _L, _P]),
     'fva_conv_pack_weights_tiled': (_I, [_P, _I, _I, _P]),
-    'fva_conv_workspace_bytes': (_L, []),
-    'fva_conv_set_workspace': (_I, [_P, _L]),
-    'fva_conv_streamk_timeouts': (_L, []),
+    'fva_conv_last_kernel': (C.c_char_p, []),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
-    'fva_conv_fwd_bn': (_I, [_D, _P, _P, _P, _P, C.POINTER(BnFwdFin), _P]),
-    'fva_bn_ticket_groups': (_I, [_I]),
-    'fva_bn_ticket_counters': (_L, [_I, _I]),
-    'fva_conv_dgrad_bn': (_I, [_D, _P, _P, _P, _P, C.POINTER(BnBwdFuse), C.POINTER(BnBwdFin), _P]),
     'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
@@ -100,6 +91,7 @@ PROTOTYPES = {
     'fva_conv_dgrad_stat_rows': (_I, [_D]),
     'fva_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _L, _P]),
     'fva_conv_wgrad_workspace': (_L, [_D]),
+    'fva_conv_wgrad_plan': (_I, [_I]),
     'fva_stem_fwd': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     'fva_stem_fwd_workspace': (_L, [_I, _I, _I, _I]),
     'fva_stem_stat_blocks': (_I, [_I, _I, _I, _I]),
@@ -163,7 +155,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_conv_patch_kernel', 'fva_bn_ticket_groups', 'fva_bn_ticket_counters', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_workspace_bytes', 'fva_conv_streamk_timeouts', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace',
+UNCHECKED = {'fva_conv_patch_kernel', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_last_kernel', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace', 'fva_conv_wgrad_plan',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k1[e] = k.k1;
         k2[e] = k.k2;
     }
-    // one padded row per block, or (EXPERIMENT FVA_APPLY_PERSIST: a grid of a few blocks per CU) a strided set of rows
+    // one padded row per block
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = row / h.Hp, yp = row - b * h.Hp;
         const int yy = yp - h.pad;
@@ -623,19 +623,12 @@ int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float*
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
     if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
-    // EXPERIMENT (FVA_APPLY_LDS=bytes): an unused dynamic LDS allocation caps the blocks per CU (160 KiB / bytes), so that a
-    // weight-gradient block of the low-priority side stream (64 KiB, one wave per SIMD) finds LDS and registers beside this pass
-    static const int cap_lds = [] { const char* e = getenv("FVA_APPLY_LDS"); return e ? atoi(e) : 0; }();
-    // EXPERIMENT (FVA_APPLY_PERSIST=k): a grid of k blocks per CU that walk the rows, so that the launch stream has no block
-    // PENDING while the pass runs and the dispatcher can place the side stream's low-priority blocks beside it
-    static const int persist = [] { const char* e = getenv("FVA_APPLY_PERSIST"); return e ? atoi(e) : 0; }();
-    const int nrows = B * h.Hp;
-    const int grid = persist > 0 && nrows > 256 * persist ? 256 * persist : nrows;
+    const int nrows = B * h.Hp, grid = nrows;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), cap_lds, s, (const bf16_t*)dz, (const bf16_t*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
                            scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h, nrows);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), cap_lds, s, (const float*)dz, (const float*)y,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dz, (const float*)y,
                            scale, shift, save_mean, save_rstd, coef, (float*)dy, h, nrows);
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return FVA_OK;

@@ -151,7 +151,9 @@ struct FvaProfileSpan {
     ~FvaProfileSpan();
 };
 
-hipStream_t fva_side_stream_peek();   // errors.hip: the low-priority side stream, NULL before the first fork
+// name of the convolution kernel the calling thread launched last (fva_conv_last_kernel: the parity tests assert which kernel they compared)
+void fva_note_kernel(const char* name);
+
 
 // diagnostic stamp buffer shared by the 8-phase kernels (set by fva_conv_debug_stamps)
 long long* fva_debug_stamps_ptr();

@@ -13,7 +13,6 @@
 #include <stddef.h>
 #include <stdlib.h>
 
-#include "bn_ticket.h"
 #include "common.h"
 
 namespace {
@@ -57,7 +56,6 @@ struct IgemmParams {
     int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
     int pt_tiles, pt_tpb;           //   tiles of the launch, consecutive tiles per block (the resident weights are staged once per block)
     FastDiv pt_div_tx, pt_div_img;  //   divisions by pt_tx and pt_tx * pt_ty
-    BnTicket tk;         // mode != 0: the statistics table (stats / bnb_part) is folded and finalised inside this launch (bn_ticket.h)
 };
 
 // coefficients of eight (bf16 chunk) consecutive channels for the fused BatchNorm-backward statistics
@@ -117,7 +115,7 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
     }
     __syncthreads();
     // wave w owns the 32 columns n0 + 32 w ..: lanes 0-31 the first sum, lanes 32-63 the second (one 128-byte line each), stored
-    // write-through so that the launch can fold the table itself (bn_ticket.h)
+    // write-through so that the launch can fold the table itself 
     const int w = tid >> 6, lane = tid & 63;
     if (w < BN / 32) {
         const int which = lane >> 5, col = w * 32 + (lane & 31);
@@ -126,11 +124,7 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
         for (int g = 0; g < G; ++g) t += red[(which * G + g) * BN + col];
         const int n = n0 + col;
         const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-        if (n < p.N) st_agent(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C), t);
-        if (p.tk.mode && n0 + w * 32 < p.N) {
-            const int nw = n0 + w * 32, subw = nw >= p.bnb_C ? 1 : 0;
-            bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), (p.bnb_row0 + mblk) * per + subw, (nw - subw * p.bnb_C) >> 5, lane);
-        }
+        if (n < p.N) *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
     }
 }
 
@@ -143,20 +137,11 @@ __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
 // The epilogue's output tile is written once and not read again by this launch: stored non-temporal it does not evict the input
 // rows that the nine taps re-read through L2 (an L2 hit arrives at 34 TB/s, a miss at 6-7: profiles/r02_dma_probe.md).  Same-box A/B
 // (bench.py, two runs each): 1041.4 / 1041.5 against 1033.3 / 1036.8 img/s, graph replay 31.8 against 32.1 ms; isolated launches of the
-// thin and 1x1 layers 4-20 % faster.  Non-temporal LOADS of the residual addend / the producer's y measured neutral (-DFVA_NT_LOADS=1).
-#ifndef FVA_NT_LOADS
-#define FVA_NT_LOADS 0
-#endif
+// thin and 1x1 layers 4-20 % faster.  Non-temporal LOADS of the residual addend / the producer's y measured neutral (round 2; removed).
 #ifndef FVA_NT_STORES
 #define FVA_NT_STORES 1
 #endif
-__device__ __forceinline__ bf16x8 ld_stream(const bf16_t* p) {
-#if FVA_NT_LOADS
-    return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load((const u32x4*)p));
-#else
-    return *(const bf16x8*)p;
-#endif
-}
+__device__ __forceinline__ bf16x8 ld_stream(const bf16_t* p) { return *(const bf16x8*)p; }
 __device__ __forceinline__ void st_stream(bf16_t* p, bf16x8 v) {
 #if FVA_NT_STORES
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);
@@ -560,12 +545,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     *(f32x4*)(red + ((1 * WMc + wr) * 16 + r) * RP + wcol0 + nt * 16 + 4 * g) = s2[nt];
                 }
                 __syncthreads();
-                if (w < BN / 32) {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
+                if (w < BN / 32) {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares 
                     const int which = lane >> 5, col = w * 32 + (lane & 31);
                     float s = 0.f;
 #pragma unroll
                     for (int k = 0; k < WMc * 16; ++k) s += red[(which * WMc * 16 + k) * RP + col];
-                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                 }
                 __syncthreads();
             } else {
@@ -600,7 +585,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     float s = 0.f;
 #pragma unroll
                     for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
-                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                 }
                 __syncthreads();
             }
@@ -682,11 +667,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     for (int k = 0; k < WMc; ++k) t += red[(which * WMc + k) * BN + col];
                     const int n = n0 + col;
                     const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-                    if (n < p.N) st_agent(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C), t);
-                    if (p.tk.mode && n0 + w * 32 < p.N) {
-                        const int nw = n0 + w * 32, subw = nw >= p.bnb_C ? 1 : 0;
-                        bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), (p.bnb_row0 + mblk) * per + subw, (nw - subw * p.bnb_C) >> 5, lane);
-                    }
+                    if (n < p.N) *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
                 }
             }
         }
@@ -723,11 +704,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
                                                 EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr, coef_tab);
     }
-    if constexpr (EPI == EPI_STATS) {
-        // the statistics table folds itself: this wave's row slice went out before the tile, so the drain in front of the ticket
-        // finds it long acknowledged
-        if (p.tk.mode && p.stats != nullptr && w < BN / 32 && n0 + w * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), mblk, (n0 >> 5) + w, lane);
-    }
     stamp(5);
 }
 
@@ -755,6 +731,7 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
     FVA_LAUNCH_CHECK("igemm_kernel");
+    fva_note_kernel(BM == 128 ? "igemm128" : "igemm256x64");
     return FVA_OK;
 }
 
@@ -956,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 64; ++k) t += red[(which * 64 + k) * RP + col];
-                if (col < p.N) st_agent(p.stats + ((int64_t)tile * 2 + which) * p.N + col, t);
+                if (col < p.N) *(p.stats + ((int64_t)tile * 2 + which) * p.N + col) = t;
             }
             __syncthreads();
         }
@@ -973,9 +950,6 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
         const int oy = ty * TH + (rr >> 5), ox = tx * TW + (rr & 31);
         return oy < p.pt_H && ox < p.pt_W ? ((int64_t)b * p.pt_H + oy) * p.pt_W + ox : (int64_t)-1;
     }, nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
-    if constexpr (EPI == EPI_STATS) {
-        if (p.tk.mode && p.stats != nullptr && w < BN / 32 && w * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), tile, w, lane);
-    }
     __syncthreads();   // the next tile's patch lands where this tile's epilogue read
     }
 }
@@ -1017,6 +991,7 @@ int launch_pconv_one(const IgemmParams& p0, int tiles, hipStream_t s) {
     }
     hipLaunchKernelGGL((pconv_kernel<CS, BN, NSL, EPI>), dim3(blocks), dim3(256), smem, s, p);
     FVA_LAUNCH_CHECK("pconv_kernel");
+    fva_note_kernel("pconv");
     return FVA_OK;
 }
 
@@ -1239,6 +1214,7 @@ int launch_pdgrad2_one(const IgemmParams& p0, int tiles, hipStream_t s) {
     }
     hipLaunchKernelGGL((pdgrad2_kernel<CS, BN, NSL, EPI>), dim3(cdiv(tiles, p.pt_tpb)), dim3(256), smem, s, p);
     FVA_LAUNCH_CHECK("pdgrad2_kernel");
+    fva_note_kernel("pdgrad2");
     return FVA_OK;
 }
 
@@ -1274,34 +1250,19 @@ int launch_pdgrad2(const IgemmParams& p0, int B, int H, int W, hipStream_t s) {
 //   WAR: every phase retires its LDS reads (lgkmcnt(0)) before its first barrier; a half-tile is re-staged at the earliest
 //        one phase after its last read, so the re-staging wave has passed a barrier that every reader reached after
 //        retiring (B-h0: read q0, staged q1; A-h0: q0 -> q2; B-h1: q1 -> q3; A-h1: q2 -> q0 of the next k-tile).
-// Stream-K (SK = true): a persistent grid of one block per CU; the launch's work, tiles x k-tiles, is cut into equal
-// contiguous runs, so a run may end inside a tile.  The block that computes a tile's FIRST k-tiles owns the tile: it is the
-// last thing that block does, and by then the blocks after it (whose runs BEGIN with the rest of that tile) have long
-// stored their fp32 partial accumulators to a slab and raised a flag; the owner adds the slabs in block order
-// (deterministic) and runs the epilogue.  Nobody waits before producing its own partial, so there is no cyclic wait;
-// polls are bounded all the same.  Hand-off: stores, vmcnt(0), barrier, agent-scope release, flag = launch epoch |
-// poll, agent-scope acquire, barrier, plain loads (cdna_hip_programming.md G16).
-struct StreamK {
-    float* slabs;        // [grid][32][512] f32x4: a block's accumulators, vector-major
-    int32_t* flags;      // [grid] launch epoch of the slab + [grid] poll time-outs (diagnostic)
-    int32_t epoch;
-    int32_t tiles;
+struct Igemm8Diag {
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8], see the kernel's stamp()
     int stamp_rows;      // blocks beyond the caller's buffer do not stamp
-    int skew;            // EXPERIMENT (FVA_IGEMM8_SKEW): every other first-round block of an XCD starts this many x 8128 cycles late
 };
+// (Round 1-3 experiments on this kernel that lost and were removed in round 4, numbers in profiles/r03_experiments.md and
+// profiles/HISTORY.md: a stream-K form with fp32 slab hand-off, a 224-row tile, a start skew between the halves of an XCD.)
 
-// MT = 16-row accumulator tiles per wave along m: 8 (a 256-row block) or 7 (224 rows).  At B = 32 the eligible layers have
-// 800 / 400 / 200 tiles of 256 x 256 for 256 CUs -- every launch ends with a round that fills 12-78 % of the chip -- while 224-row
-// tiles give 915 / 458 / 232: the same number of rounds of tiles that each cost 7/8 of the MFMA work (use_igemm8_mt picks).  The
-// LDS image keeps its 128-row half-tiles (the second half of a wave row holds 48 live rows; the other 16 are staged and never
-// read), so the staging, the swizzle and every hazard argument above are unchanged.
 #ifndef FVA_EPI_STAMPS
 #define FVA_EPI_STAMPS 0     // 1: the four diagnostic stamps bracket the epilogue's phases instead of the tile's (tools/tile_timing.py)
 #endif
-template <int EPI, bool SK, int MT>
-__global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const StreamK sk) {
-    static_assert(MT >= 5 && MT <= 8, "4 tiles in the first half of a wave row, 1-4 in the second");
+template <int EPI>
+__global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const Igemm8Diag sk) {
+    constexpr int MT = 8;                             // 16-row accumulator tiles per wave along m
     constexpr int WM = 16 * MT;                       // rows of a wave row
     constexpr int BM = 2 * WM, BN = 256, NT = 512, BK = 64;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;   // bytes
@@ -1321,8 +1282,6 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #endif
 
     const int nwg = gridDim.x, bid = blockIdx.x;
-    if (sk.skew && bid < 256 && ((bid >> 3) & 1))        // the rounds of the two halves then store their tiles at different times
-        for (int i = 0; i < sk.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int KT = p.ktiles;
@@ -1346,23 +1305,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
     const int co0 = (g ^ sr) << 4, co1 = ((4 + g) ^ sr) << 4;        // byte offsets of the two k-steps' 16-B chunks
     const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
 
-    // this block's run of (tile, k-tile) units (the host keeps tiles * k-tiles * grid below 2^31)
-    int u, u_end;
-    static_assert(!SK || MT == 8, "the stream-K slabs hold whole 256-row tiles");
-    if constexpr (SK) {
-        const int total = sk.tiles * KT;
-        u = (int)((int64_t)total * logical / nwg);
-        u_end = (int)((int64_t)total * (logical + 1) / nwg);
-    } else {
-        u = logical * KT;
-        u_end = u + KT;
-    }
-
-    for (; u < u_end;) {
-        const int tile = u / KT;
-        const int kt0 = u - tile * KT;
-        const int kt1 = KT - kt0 < u_end - u ? KT : kt0 + (u_end - u);
-        u += kt1 - kt0;
+    {
+        const int tile = logical, kt0 = 0, kt1 = KT;
         const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
         const int m0 = mblk * BM, n0 = nblk * BN;
         __syncthreads();   // ktab is written / the previous tile's epilogue is done with LDS
@@ -1377,7 +1321,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int rh = (i * 8 + w) * 8 + lrow;                   // row inside the half-tile, 0..127
-                int m = m0 + (rh >> 6) * WM + h * 64 + (rh & 63);     // MT < 8: rows 16 (MT - 4) .. 63 of the second half are never read
+                int m = m0 + (rh >> 6) * WM + h * 64 + (rh & 63);
                 m = m < p.M ? m : p.M - 1;
                 const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
                 const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
@@ -1390,7 +1334,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                 b_off[h][i] = ((uint32_t)n * (uint32_t)p.C + chunk * 8) * 2;
             }
 
-        // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1; kt is absolute, the LDS buffer alternates from this run's first k-tile
+        // kind: 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1; the LDS buffer alternates with the k-tile
         auto stage = [&](int kind, int kt, int koff) {
             char* dst = smem + ((kt - kt0) & 1) * BUF + kind * HALF + w * 1024;
             const uint32_t off = (uint32_t)koff * 2;   // tap offsets may be "negative": wraps in 32 bits
@@ -1416,10 +1360,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
             const char* q = buf + h * HALF + a_row;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                if (h * 4 + mt < MT) {
-                    af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
-                    af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
-                }
+                af[mt][0] = *(const bf16x8*)(q + mt * 2048 + co0);
+                af[mt][1] = *(const bf16x8*)(q + mt * 2048 + co1);
             }
         };
         auto read_b = [&](const char* buf, int h, bf16x8 (&bf)[2][2]) {
@@ -1438,9 +1380,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        if (ha * 4 + mt < MT)
-                            acc[ha * 4 + mt][hb * 2 + nt] =      // operands swapped: D = (B^T A^T), a lane's four accumulators are four adjacent COLUMNS
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][ks], af[mt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
+                        acc[ha * 4 + mt][hb * 2 + nt] =      // operands swapped: D = (B^T A^T), a lane's four accumulators are four adjacent COLUMNS
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][ks], af[mt][ks], acc[ha * 4 + mt][hb * 2 + nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
         auto retire_reads_then_barrier = [&]() {
@@ -1517,57 +1458,6 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         asm volatile("" : "+v"(tid_e));
         const int lane_e = tid_e & 63, r_e = lane_e & 15, g_e = lane_e >> 4, wr_e = tid_e >> 8, wc_e = (tid_e >> 6) & 3;
 
-        if constexpr (SK) {
-            if (kt0 > 0) {
-                // the rest of a tile another block owns: hand the partial accumulators over and go on
-                f32x4* slab = (f32x4*)sk.slabs + (int64_t)logical * (32 * NT) + tid_e;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) slab[(i * 4 + j) * NT] = acc[i][j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(sk.flags + logical, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                continue;
-            }
-            if (kt1 < KT) {
-                // owner of a tile that continues in the following blocks' runs: add their slabs in block order
-                const int64_t total = (int64_t)sk.tiles * KT;
-                int remaining = KT - kt1;
-                for (int j = logical + 1; remaining > 0 && j < nwg; ++j) {
-                    const int64_t run = total * (j + 1) / nwg - total * j / nwg;
-                    remaining -= run < remaining ? (int)run : remaining;
-                    if (tid == 0) {
-                        int spins = 0;
-                        while (__hip_atomic_load(sk.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch && spins < (1 << 22)) {
-                            __builtin_amdgcn_s_sleep(16);
-                            ++spins;
-                        }
-                        if (spins >= (1 << 22)) __hip_atomic_fetch_add(sk.flags + nwg + logical, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __syncthreads();
-                    const f32x4* slab = (const f32x4*)sk.slabs + (int64_t)j * (32 * NT) + tid_e;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {   // four vectors at a time: the accumulators already fill the register file
-                        f32x4 t4[4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) t4[jj] = slab[(i * 4 + jj) * NT];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[i][jj] += t4[jj];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        }
-
         // The wave's 128x64 accumulator.  With the MFMA operands swapped, acc[mi][ni] of lane (r, g) is the 1 x 4 piece
         //   row  wr * WM + mi * 16 + r,   columns  wc * 64 + ni * 16 + 4 g .. + 3
         // of the block tile: four adjacent output channels of one pixel -- one packed 8-byte LDS write instead of four 2-byte ones
@@ -1601,12 +1491,12 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                     *(f32x4*)(red + ((1 * 2 + wr_e) * 16 + r_e) * RP + col_e + ni * 16) = s2[ni];
                 }
                 __syncthreads();
-                {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares (bn_ticket.h)
+                {   // wave w: columns n0 + 32 w .., lanes 0-31 the sum, lanes 32-63 the sum of squares 
                     const int which = lane_e >> 5, col = (tid_e >> 6) * 32 + (lane_e & 31);
                     float s = 0.f;
 #pragma unroll
                     for (int i = 0; i < 32; ++i) s += red[(which * 32 + i) * RP + col];
-                    if (n0 + col < p.N) st_agent(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col, s);
+                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                 }
                 __syncthreads();
             }
@@ -1642,31 +1532,16 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #endif
         store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid_e, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
                                                 nullptr, nullptr, EPI == EPI_BNB ? coef_tab : nullptr);
-        if constexpr (EPI == EPI_STATS) {
-            if (p.tk.mode && p.stats != nullptr && n0 + (tid_e >> 6) * 32 < p.N) bn_ticket_arrive(bn_ticket_kernarg(offsetof(IgemmParams, tk)), mblk, (n0 >> 5) + (tid_e >> 6), lane_e);
-        }
     }
     stamp(3);
 }
 
 constexpr int IGEMM8_SMEM = 256 * (256 * 2 + 16) + 4096 + 4096;   // the epilogue's transposed tile (> 2 staging buffers) + k table + bnb_fill_lds table
 
-// Stream-K scratch, registered once by the caller (fva_conv_set_workspace): [grid] slabs of 256 KiB + flags.
-struct SkWorkspace {
-    float* slabs = nullptr;
-    int32_t* flags = nullptr;
-    int grid = 0;
-    int32_t epoch = 0;
-};
-SkWorkspace g_sk;
-constexpr int64_t SK_SLAB_BYTES = 512ll * 128 * 4;
-
-// Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, and
-//  * with stream-K enabled (experiment, see streamk_mode): at least 16 k-tile units per CU (any tile count);
-//  * otherwise at least 128 tiles of 256x256 and either a long reduction (>= 16 k-tiles, FVA_IGEMM8_MINKT: the per-tile prologue / epilogue
-//    is not overlapped by a second block as in the 128x128 kernel) or at most one round of tiles.
-// Measured without stream-K (tools/check_igemm8.py, B = 32): 256->512 @40^2 161 -> 129 us, 512->1024 @20^2 154 -> 118 us,
-// 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.  FVA_IGEMM8=0 turns the kernel off.
+// Eligible bf16 layers go to the 8-phase kernel: N a multiple of 256, full 64-channel k-tiles, at least 128 tiles of 256x256 and
+// either a long reduction (>= 16 k-tiles, FVA_IGEMM8_MINKT: the per-tile prologue / epilogue is not overlapped by a second block as
+// in the 128x128 kernel) or at most one round of tiles.  Measured (tools/check_igemm8.py, B = 32): 256->512 @40^2 161 -> 129 us,
+// 512->1024 @20^2 154 -> 118 us, 128->256 @80^2 (18 k-tiles, 800 tiles) 158 -> 157 us.  FVA_IGEMM8=0 turns the kernel off.
 inline bool igemm8_enabled() {
     static bool v = [] {
         const char* e = getenv("FVA_IGEMM8");
@@ -1674,48 +1549,15 @@ inline bool igemm8_enabled() {
     }();
     return v;
 }
-// Stream-K is OFF unless FVA_STREAMK is set (1 = on, 2 = also when the tiles divide evenly: measurement aid) and a
-// workspace is registered.  Measured (tools/check_igemm8.py, CHECK_STREAMK=1): correct and deterministic, but slower than
-// whole tiles at B = 32 (256->512 @40^2: 157 us vs 128 us) -- the per-run pipeline refills, the extra epilogues and the
-// slab hand-off cost more than the 22 % of idle CU time they remove, most of which the second, lighter round of whole
-// tiles already gets back through less contention.  Kept as an experiment for larger grids / batches.
-inline int streamk_mode() {
-    static int v = [] {
-        const char* e = getenv("FVA_STREAMK");
-        return e ? atoi(e) : 0;
-    }();
-    return g_sk.grid > 0 ? v : 0;
-}
-inline bool use_streamk(int64_t tiles, int64_t ktiles) {
-    const int mode = streamk_mode();
-    return mode && tiles * ktiles >= 16ll * g_sk.grid && (mode == 2 || tiles % g_sk.grid != 0);
-}
 // in_pixels: pixels of the (halo) input tensor -- the kernel addresses both operands with 32-bit byte offsets
 inline bool use_igemm8(int dtype, int64_t M, int N, int C, int ntaps, int64_t in_pixels) {
     if (!igemm8_enabled() || dtype != FVA_BF16 || N % 256 || C % 64) return false;
     if (in_pixels * C * 2 >= (1ll << 31) || (int64_t)(ntaps + 1) * N * C * 2 >= (1ll << 31)) return false;
     const int64_t ktiles = (int64_t)ntaps * (C / 64), tiles = (int64_t)cdiv(M, 256) * (N / 256);
     if (ktiles > 496 || ktiles < 8) return false;
-    if (use_streamk(tiles, ktiles)) return true;
     if (tiles < 128) return false;
     static const int min_kt = [] { const char* e = getenv("FVA_IGEMM8_MINKT"); return e ? atoi(e) : 16; }();
     return ktiles >= min_kt || tiles <= 256;
-}
-
-// Rows of the 8-phase kernel's block for a launch of M rows, N columns: 224 when that needs fewer MFMA-rounds than 256 -- rounds of
-// tiles on the chip's CUs x the tile's share of the work (ceil(tiles / CUs) x rows).  FVA_IGEMM8_BM=256 keeps the old tile (A/B aid).
-inline int igemm8_bm(int64_t M, int N, int64_t ktiles) {
-    static const int force = [] { const char* e = getenv("FVA_IGEMM8_BM"); return e ? atoi(e) : 0; }();
-    if (force == 224) return 224;
-    if (force != 1) return 256;            // measured equal or slower (profiles/r03_experiments.md): the chip is power-limited, not fill-limited
-    if (use_streamk((int64_t)cdiv(M, 256) * (N / 256), ktiles)) return 256;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
-    const int64_t t8 = (int64_t)cdiv(M, 256) * (N / 256), t7 = (int64_t)cdiv(M, 224) * (N / 256);
-    return cdiv(t7, cus) * 7 < cdiv(t8, cus) * 8 ? 224 : 256;
 }
 
 long long* g_stamps = nullptr;   // fva_conv_debug_stamps
@@ -1725,31 +1567,17 @@ template <int EPI>
 int launch_igemm8(const IgemmParams& p, hipStream_t s) {
     IgemmParams q = p;
     q.nblocks = p.N / 256;
-    const int bm = igemm8_bm(p.M, p.N, p.ktiles);
-    const int tiles = cdiv(p.M, bm) * q.nblocks;
+    const int tiles = cdiv(p.M, 256) * q.nblocks;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM8_SMEM);
         attr_done = true;
     }
-    StreamK sk{};
+    Igemm8Diag sk{};
     sk.stamps = g_stamps;
     sk.stamp_rows = g_stamp_rows;
-    static const int skew = [] { const char* e = getenv("FVA_IGEMM8_SKEW"); return e ? atoi(e) : 0; }();
-    sk.skew = tiles > 256 ? skew : 0;
-    if (bm == 256 && use_streamk(tiles, p.ktiles)) {
-        sk.slabs = g_sk.slabs;
-        sk.flags = g_sk.flags;
-        sk.epoch = ++g_sk.epoch;
-        sk.tiles = tiles;
-        hipLaunchKernelGGL((igemm8_kernel<EPI, true, 8>), dim3(g_sk.grid), dim3(512), IGEMM8_SMEM, s, q, sk);
-    } else if (bm == 224) {
-        hipLaunchKernelGGL((igemm8_kernel<EPI, false, 7>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
-    } else {
-        hipLaunchKernelGGL((igemm8_kernel<EPI, false, 8>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
-    }
+    hipLaunchKernelGGL((igemm8_kernel<EPI>), dim3(tiles), dim3(512), IGEMM8_SMEM, s, q, sk);
+    fva_note_kernel("igemm8");
     FVA_LAUNCH_CHECK("igemm8_kernel");
     return FVA_OK;
 }
@@ -2030,32 +1858,6 @@ int packed_taps(const fva_conv_desc* d, int for_dgrad) {
 
 }  // namespace
 
-extern "C" {
-
-int64_t fva_conv_workspace_bytes(void) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus < 8) return 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return (int64_t)cus * SK_SLAB_BYTES + (int64_t)cus * 2 * 4;
-}
-
-int fva_conv_set_workspace(void* ws, int64_t bytes) {
-    if (!ws) {
-        g_sk = SkWorkspace();
-        return FVA_OK;
-    }
-    const int64_t need = fva_conv_workspace_bytes();
-    if (need <= 0 || bytes < need) return fva_fail(FVA_ERR_ARG, "fva_conv_set_workspace: %lld bytes given, %lld needed", (long long)bytes, (long long)need);
-    const int cus = (int)(need / (SK_SLAB_BYTES + 8));
-    g_sk.slabs = (float*)ws;
-    g_sk.flags = (int32_t*)((char*)ws + (int64_t)cus * SK_SLAB_BYTES);
-    g_sk.grid = cus;
-    g_sk.epoch = 0;
-    return FVA_OK;
-}
-
-}  // extern "C"
 long long* fva_debug_stamps_ptr() { return g_stamps; }
 int fva_debug_stamps_rows() { return g_stamp_rows; }
 extern "C" {
@@ -2071,16 +1873,6 @@ int fva_conv_debug_stamps(void* stamps, int32_t rows) {
     g_stamps = (long long*)stamps;
     g_stamp_rows = stamps ? rows : 0;
     return FVA_OK;
-}
-
-int64_t fva_conv_streamk_timeouts(void) {
-    if (!g_sk.grid) return 0;
-    int32_t host[1024];
-    const int n = g_sk.grid < 1024 ? g_sk.grid : 1024;
-    if (hipMemcpy(host, g_sk.flags + g_sk.grid, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    int64_t t = 0;
-    for (int i = 0; i < n; ++i) t += host[i];
-    return t;
 }
 
 int64_t fva_conv_packed_elems(const fva_conv_desc* d, int for_dgrad) {
@@ -2126,7 +1918,7 @@ int32_t fva_conv_stat_blocks(const fva_conv_desc* d) {
     const int64_t M = (int64_t)d->B * OH * OW;
     const int64_t in_img = (int64_t)(d->H + 2 * d->in_pad) * (d->W + 2 * d->in_pad);
     if (!halfrow_mode(d->dtype, d->Cin) && use_igemm8(d->dtype, M, d->Cout, d->Cin, d->ksize * d->ksize, (M / ((int64_t)OH * OW) + 1) * in_img))
-        return cdiv(M, igemm8_bm(M, d->Cout, (int64_t)d->ksize * d->ksize * (d->Cin / 64)));
+        return cdiv(M, 256);
     return cdiv(M, tile_bm(d->dtype, (int)M, d->Cout));
 }
 
@@ -2157,44 +1949,13 @@ static int setup_fwd(const fva_conv_desc* d, IgemmParams& p, const char* who) {
             ++nt;
         }
     p.tap_w[nt] = k * k;  // zero tap (present in packed weights when needed)
-    {   // EXPERIMENT (results wrong): every tap reads the centre tap's pixels -> what the L2 -> LDS re-reads of the nine taps cost
-        static const bool centre = [] { const char* e = getenv("FVA_TAP_CENTRE"); return e && atoi(e) != 0; }();
-        if (centre) for (int i = 0; i < nt; ++i) p.tap_pix[i] = p.tap_pix[nt / 2];
-    }
     finish_taps(p, nt, d->dtype);
     p.out_dense = 1;
     p.out_pitch = d->Cout;
     return FVA_OK;
 }
 
-int32_t fva_bn_ticket_groups(int32_t rows) { return rows > 0 ? cdiv(rows, bn_ticket_group_rows(rows)) : 0; }
-int64_t fva_bn_ticket_counters(int32_t rows, int32_t C) { return rows > 0 && C > 0 ? (int64_t)(fva_bn_ticket_groups(rows) + 1) * cdiv(C, 32) : 0; }
-
-// common part of the two ticket descriptors: geometry of the table and the scratch the fold needs
-static int ticket_base(BnTicket& t, int mode, int rows, int C, int64_t count, int32_t* counters, double* group_sums, const float* part,
-                       const char* who) {
-    if (C % 32) return fva_fail(FVA_ERR_ARG, "%s: in-launch BatchNorm finalisation needs C %% 32 == 0 (C = %d)", who, C);
-    if (!counters || !part || rows < 1) return fva_fail(FVA_ERR_ARG, "%s: in-launch BatchNorm finalisation: null counters / table", who);
-    t = BnTicket();
-    t.mode = mode;
-    t.rows = rows;
-    t.G = bn_ticket_group_rows(rows);
-    t.ngroups = cdiv(rows, t.G);
-    if (t.ngroups > 1 && !group_sums) return fva_fail(FVA_ERR_ARG, "%s: %d row groups need group_sums", who, t.ngroups);
-    t.C = C;
-    t.counters = counters;
-    t.gsum = group_sums;
-    t.part = part;
-    t.count = (double)count;
-    return FVA_OK;
-}
-
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream) {
-    return fva_conv_fwd_bn(d, x, w_fwd, y, stats_partial, nullptr, stream);
-}
-
-int fva_conv_fwd_bn(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, const fva_bn_fwd_fin* fin,
-                    void* stream) {
     IgemmParams p;
     int rc = setup_fwd(d, p, "fva_conv_fwd");
     if (rc) return rc;
@@ -2204,17 +1965,6 @@ int fva_conv_fwd_bn(const fva_conv_desc* d, const void* x, const void* w_fwd, vo
     p.wt = w_fwd;
     p.out = y;
     p.stats = stats_partial;
-    if (fin) {
-        if (!stats_partial || !fin->gamma || !fin->beta || !fin->save_mean || !fin->save_rstd || !fin->scale || !fin->shift)
-            return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_bn: null pointer");
-        rc = ticket_base(p.tk, 1, fva_conv_stat_blocks(d), d->Cout, p.M, fin->counters, fin->group_sums, stats_partial, "fva_conv_fwd_bn");
-        if (rc) return rc;
-        p.tk.gamma = fin->gamma; p.tk.beta = fin->beta;
-        p.tk.running_mean = fin->running_mean; p.tk.running_var = fin->running_var;
-        p.tk.nbt = (long long*)fin->num_batches_tracked;
-        p.tk.momentum = fin->momentum; p.tk.eps = fin->eps;
-        p.tk.save_mean = fin->save_mean; p.tk.save_rstd = fin->save_rstd; p.tk.scale = fin->scale; p.tk.shift = fin->shift;
-    }
     FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return launch_pconv<EPI_STATS>(p, d->B, d->H, d->W, false, (hipStream_t)stream);
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
@@ -2287,7 +2037,7 @@ int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const
 
 // row blocks (BM of the tile the dispatcher picks) of ONE dgrad launch with m rows, n columns, reduction over c channels x ntaps
 static int dgrad_launch_rows(const fva_conv_desc* d, int64_t m, int n, int c, int ntaps, int64_t in_pixels) {
-    if (!halfrow_mode(d->dtype, c) && use_igemm8(d->dtype, m, n, c, ntaps, in_pixels)) return cdiv(m, igemm8_bm(m, n, (int64_t)ntaps * (c / 64)));
+    if (!halfrow_mode(d->dtype, c) && use_igemm8(d->dtype, m, n, c, ntaps, in_pixels)) return cdiv(m, 256);
     return cdiv(m, tile_bm(d->dtype, (int)m, n));
 }
 
@@ -2312,16 +2062,11 @@ int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d) {
 }
 
 int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream) {
-    return fva_conv_dgrad_bn(d, dy, w_dgrad, dx, addend, nullptr, nullptr, stream);
+    return fva_conv_dgrad_bnstats(d, dy, w_dgrad, dx, addend, nullptr, stream);
 }
 
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* f, void* stream) {
-    return fva_conv_dgrad_bn(d, dy, w_dgrad, dx, addend, f, nullptr, stream);
-}
-
-int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
-                      const fva_bn_bwd_fuse* f, const fva_bn_bwd_fin* fin, void* stream) {
     int rc = check_desc(d, "fva_conv_dgrad");
     if (rc) return rc;
     rc = check_red_channels(d->dtype, d->Cout, "fva_conv_dgrad");
@@ -2349,17 +2094,6 @@ int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgra
         p.bnb_part = f->partial;
         p.bnb_row0 = 0;
         p.bnb_C = d->Cin;
-        if (fin) {
-            if (!fin->gamma || !fin->dgamma || !fin->dbeta || !fin->coef) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bn: null pointer");
-            rc = ticket_base(p.tk, 2, fva_conv_dgrad_stat_rows(d), d->Cin, (int64_t)d->B * d->H * d->W, fin->counters, fin->group_sums,
-                             f->partial, "fva_conv_dgrad_bn");
-            if (rc) return rc;
-            p.tk.gamma = fin->gamma; p.tk.rstd = f->rstd;
-            p.tk.dgamma = fin->dgamma; p.tk.dbeta = fin->dbeta; p.tk.coef = fin->coef;
-            p.tk.accumulate = fin->accumulate;
-        }
-    } else if (fin) {
-        return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bn: a finalisation descriptor needs the fused statistics (fuse != NULL)");
     }
     const int64_t in_pixels = (int64_t)(d->B + 1) * (OH + 2 * d->dy_pad) * (OW + 2 * d->dy_pad);
     if (s == 1) {

@@ -24,20 +24,9 @@ __device__ __forceinline__ void wait_vmcnt_n() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// -DFVA_NT_SLAB=1 writes the partial tiles non-temporal (so that they do not evict the operand rows other blocks re-read).  Measured
-// (same box, two bench runs each): it LOSES -- wgrad class 8.5 -> 9.15 ms, 1022 -> 1017 img/s: the reduce kernel that follows reads
-// the slabs back, and finds them in cache only when they were written the ordinary way.  (The convolution epilogue's output tile is
-// the opposite case: conv_igemm.hip st_stream.)
-#ifndef FVA_NT_SLAB
-#define FVA_NT_SLAB 0
-#endif
-__device__ __forceinline__ void slab_store(float* p, float v) {
-#if FVA_NT_SLAB
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+// The partial tiles are written with ordinary stores: non-temporal ones LOSE (measured in round 2: wgrad class 8.5 -> 9.15 ms), because
+// the reduce kernel that follows finds the slabs in cache only when they were written the ordinary way.
+__device__ __forceinline__ void slab_store(float* p, float v) { *p = v; }
 
 struct WgradParams {
     const void* x;
@@ -438,47 +427,6 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
 
-#ifndef FVA_WGRAD8_PLAIN
-#define FVA_WGRAD8_PLAIN 0    // 1: EXPERIMENT -- a plain two-buffer loop (one barrier per k-step, the whole next step's LDS-DMA issued at its start)
-#endif
-#if FVA_WGRAD8_PLAIN
-    // tools/probe_wg4.hip runs this loop shape at 1.66 us per k-step with an operand stream shared by five blocks of an XCD
-    uint32_t d1[2], x1[2];
-    {
-        uint32_t d0[2], x0[2];
-        decode(0, d0, x0);
-        stage(2, 0, d0, x0); stage(0, 0, d0, x0); stage(3, 0, d0, x0); stage(1, 0, d0, x0);
-    }
-    decode(1, d1, x1);
-    wait_vmcnt_n<0>();
-    __builtin_amdgcn_s_barrier();
-    stamp(1);
-    auto retire_reads = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int s = 0; s < steps; ++s) {
-        const int cur = s & 1;
-        const uint32_t boff = (uint32_t)cur * BUF;
-        if (s + 1 < steps) { stage(2, cur ^ 1, d1, x1); stage(0, cur ^ 1, d1, x1); stage(3, cur ^ 1, d1, x1); stage(1, cur ^ 1, d1, x1); }
-        read_b(boff, K2{}, b0);
-        read_a(boff, K0{});
-        retire_reads();
-        mma(0, 0, b0);
-        read_b(boff, K3{}, b1);
-        retire_reads();
-        mma(0, 1, b1);
-        read_a(boff, K1{});
-        retire_reads();
-        mma(1, 1, b1);
-        decode(s + 2, d1, x1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 0, b0);
-        wait_vmcnt_n<0>();
-        __builtin_amdgcn_s_barrier();
-    }
-    stamp(2);
-#else
     // ---- prologue: step 0 complete, three half-tiles of step 1 in flight; offsets of steps 1 and 2 decoded ------------
     uint32_t d1[2], x1[2], d2[2], x2[2];
     {
@@ -536,7 +484,6 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgradParams p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     stamp(2);
-#endif
 
     // ---- partial tile -> slab[ks][tap][N][C] --------------------------------------------------------------------------
     float* out = p.slab + (int64_t)ks * p.ntaps * p.N * p.C;
@@ -599,10 +546,6 @@ struct PwgradParams {
     FastDiv div_tx, div_img;
 };
 
-#ifndef FVA_PWGRAD_ABL
-#define FVA_PWGRAD_ABL 0      // timing experiments (results wrong): 1 = staging only, 2 = only the first patch of a run is staged,
-                              // 3 = as 2 without the fragment reads (MFMAs only), 4 = as 2 without the MFMAs (fragment reads only)
-#endif
 template <int V>
 struct IntC {
     static constexpr int value = V;
@@ -685,9 +628,6 @@ __global__ __launch_bounds__(256, (C == 32 && TH * STRIDE <= 4) ? 3 : 2) void pw
         const int tyi = (int)fd_div((uint32_t)trem, p.div_tx), txi = trem - tyi * p.tx;
         const int oy0 = tyi * TH, ox0 = txi * TW;
         __syncthreads();                                   // every wave is done reading the previous patch
-#if FVA_PWGRAD_ABL >= 2
-        if (tile == t_begin)
-#endif
         {
         // ---- stage X: LDS row py * XW + lcol <- padded input pixel (STRIDE * oy0 + x_y0 + py, STRIDE * ox0 + x_x0 + px) ----
         {
@@ -729,45 +669,29 @@ __global__ __launch_bounds__(256, (C == 32 && TH * STRIDE <= 4) ? 3 : 2) void pw
         wait_vm0();
         __syncthreads();
         // ---- TH k-steps of 32 pixels (one patch row each) ----
-#if FVA_PWGRAD_ABL != 1
         static_for<0, TH>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             constexpr int XO = r * STRIDE * XW * XROWB, YO = r * 32 * YROWB;
             // column tiles in groups of CG: the 64-channel form holds 144 accumulators, and nine B fragments on top of them spill
             constexpr int CG = C == 32 ? 9 : 5;
             bf16x8 af[NT];
-#if FVA_PWGRAD_ABL == 3
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) af[nt] = __builtin_bit_cast(bf16x8, u32x4{ya[nt], ya[nt] + r, ya[nt], ya[nt]});
-#else
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) af[nt] = cat8(tr_read<YO>(ya[nt]), tr_read<YO + 4 * YROWB>(ya[nt]));
-#endif
 #pragma unroll
             for (int c0 = 0; c0 < CT; c0 += CG) {
                 bf16x8 bfr[CG];
 #pragma unroll
-#if FVA_PWGRAD_ABL == 3
-                for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) bfr[ct - c0] = __builtin_bit_cast(bf16x8, u32x4{xa[ct][0], xa[ct][1], xa[ct][0] + r, xa[ct][1]});
-#else
                 for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) bfr[ct - c0] = cat8(tr_read<XO>(xa[ct][0]), tr_read<XO>(xa[ct][1]));
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-#if FVA_PWGRAD_ABL == 4
-#pragma unroll
-                for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct) acc[0][ct] += __builtin_bit_cast(f32x4, bfr[ct - c0]) + __builtin_bit_cast(f32x4, af[ct % NT]);
-#else
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int ct = c0; ct < (c0 + CG < CT ? c0 + CG : CT); ++ct)
                         acc[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[ct - c0], acc[nt][ct], 0, 0, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-#endif
     }
     // ---- partial gradient -> slab[run][tap][Cout][Cin] ----
     float* out = p.slab + (int64_t)run * 9 * NTOT * C;
@@ -953,10 +877,13 @@ inline bool use_wgrad8(const fva_conv_desc* d) {
     return M * units >= 24ll * 64 * 256;
 }
 
-// beside: the launch goes to the library's low-priority side stream and shares the chip with the rest of the backward pass: planned
-// for HALF the resident block slots, its fewer, longer blocks leave CUs to the launch stream and write half the slab bytes.  Measured
-// in the whole step (tools/wgrad_slots.sh, same box, after the patch kernel): 29.94 ms with 128 / 256 slots against 30.2 with
-// 256 / 512; alone on a stream the same plan is slower (33.8 against 31.0 ms single-stream), hence the switch.
+// beside: the weight gradients run on the library's low-priority side stream and share the chip with the rest of the backward pass:
+// planned for HALF the resident block slots, their fewer, longer blocks leave CUs to the launch stream and write half the slab bytes.
+// Measured in the whole step (round 3, same box): 29.94 ms with 128 / 256 slots against 30.2 with 256 / 512; alone on a stream the same
+// plan is slower (33.8 against 31.0 ms single-stream).  The split factor fixes the fp32 summation order of dW, so WHICH plan is used is
+// a process-wide setting (fva_conv_wgrad_plan; ops sets it together with the side stream), never a property of the stream a launch
+// happens to be given: a layer that falls back to the launch stream, or a step captured on one stream, sums in the same order.
+int g_wgrad_plan_beside = 0;
 int plan_wgrad(const fva_conv_desc* d, WgradPlan& pl, bool beside = false) {
     pl.tile = d->dtype == FVA_BF16 ? (use_wgrad8(d) ? 256 : 128) : 64;
     pl.OH = (d->H - 1) / d->stride + 1;
@@ -1054,6 +981,7 @@ int launch_pwgrad(const PwgradParams& p, int grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((pwgrad_kernel<C, N, STRIDE, TH>), dim3(grid), dim3(256), smem, s, p);
     FVA_LAUNCH_CHECK("pwgrad_kernel");
+    fva_note_kernel("pwgrad");
     return FVA_OK;
 }
 template <int C, int N>
@@ -1080,6 +1008,12 @@ int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d) {
     return (int64_t)ks * pl.ntaps * d->Cout * d->Cin * 4;
 }
 
+int fva_conv_wgrad_plan(int beside) {
+    const int prev = g_wgrad_plan_beside;
+    if (beside == 0 || beside == 1) g_wgrad_plan_beside = beside;
+    return prev;
+}
+
 int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace,
                    int64_t workspace_bytes, void* stream) {
     if (!d || !x || !dy || !dw || !workspace) return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: null pointer");
@@ -1095,7 +1029,7 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         (int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cout * esz >= (1ll << 32))
         return fva_fail(FVA_ERR_ARG, "fva_conv_wgrad: operand larger than 4 GiB (32-bit byte offsets)");
     WgradPlan pl;
-    const bool beside = stream != nullptr && (hipStream_t)stream == fva_side_stream_peek();
+    const bool beside = g_wgrad_plan_beside != 0;
     plan_wgrad(d, pl, beside);
     FvaProfileSpan span(2 | (d->ksize << 8), 2.0 * pl.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     if (use_pwgrad(d)) {
@@ -1166,12 +1100,17 @@ int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float*
         p.stamps = fva_debug_stamps_ptr();
         p.stamp_rows = fva_debug_stamps_rows();
         hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(512), 2 * 4 * 64 * 256, s, p);
-    } else if (d->dtype == FVA_BF16 && d->Cout <= 64 && wgrad_thin_enabled())
+        fva_note_kernel("wgrad8");
+    } else if (d->dtype == FVA_BF16 && d->Cout <= 64 && wgrad_thin_enabled()) {
         hipLaunchKernelGGL((wgrad_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, p);
-    else if (d->dtype == FVA_BF16)
+        fva_note_kernel("wgrad128thin");
+    } else if (d->dtype == FVA_BF16) {
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, p);
-    else
+        fva_note_kernel("wgrad128");
+    } else {
         hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), smem, s, p);
+        fva_note_kernel("wgrad64f32");
+    }
     FVA_LAUNCH_CHECK("wgrad_kernel");
     const int64_t nc = (int64_t)d->Cout * d->Cin;
     static const bool reduce4 = [] { const char* e = getenv("FVA_WGRAD_REDUCE4"); return !e || atoi(e) != 0; }();   // =0: A/B aid

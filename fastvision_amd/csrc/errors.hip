@@ -2,6 +2,9 @@
 thread_local char fva_err_buf[512] = "";
 extern "C" const char* fva_last_error(void) { return fva_err_buf; }
 extern "C" int fva_version(void) { return 1; }
+static thread_local const char* g_last_kernel = "";
+void fva_note_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* fva_conv_last_kernel(void) { return g_last_kernel; }
 
 // ---- profiling spans --------------------------------------------------------------------------------------------------
 #include <vector>
@@ -74,8 +77,27 @@ namespace {
 hipStream_t g_side = nullptr;
 int g_side_dev = -1;
 hipEvent_t g_side_ev[64];
+bool g_side_ev_ready = false;
 int g_side_next = 0;
 hipEvent_t side_event() { return g_side_ev[g_side_next++ & 63]; }
+
+// a fresh lowest-priority stream (and, once per process, the fork / join events); the library's side stream is replaced only on success
+int side_stream_create(hipStream_t* out, const char* who) {
+    int least = 0, greatest = 0;
+    hipStream_t s = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess)
+        return fva_fail(FVA_ERR_LAUNCH, "%s: cannot create the side stream", who);
+    if (!g_side_ev_ready) {
+        for (auto& e : g_side_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(s);
+                return fva_fail(FVA_ERR_LAUNCH, "%s: hipEventCreate failed", who);
+            }
+        g_side_ev_ready = true;
+    }
+    *out = s;
+    return FVA_OK;
+}
 }  // namespace
 
 extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
@@ -85,13 +107,11 @@ extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
     if (g_side && dev != g_side_dev)   // one process per GPU is the model; a second device in the same process stays on its launch stream
         return fva_fail(FVA_ERR_ARG, "fva_side_stream_fork: the side stream belongs to device %d, current device is %d", g_side_dev, dev);
     if (!g_side) {
+        hipStream_t s = nullptr;
+        const int rc = side_stream_create(&s, "fva_side_stream_fork");
+        if (rc) return rc;
+        g_side = s;
         g_side_dev = dev;
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess)
-            return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_fork: cannot create the side stream");
-        for (auto& e : g_side_ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_fork: hipEventCreate failed");
     }
     hipEvent_t e = side_event();
     if (hipEventRecord(e, (hipStream_t)main_stream) != hipSuccess || hipStreamWaitEvent(g_side, e, 0) != hipSuccess)
@@ -100,21 +120,22 @@ extern "C" int fva_side_stream_fork(void* main_stream, void** side_stream) {
     return FVA_OK;
 }
 
-// the library's side stream, or NULL before the first fork (conv_wgrad.hip plans its split-K for the stream it is launched on)
-hipStream_t fva_side_stream_peek() { return g_side; }
-
-// Drop the side stream: the next fork creates a fresh one.  How a HIP stream maps onto the hardware queues is the runtime's choice at
-// creation; on some boxes / processes the low-priority stream lands where it no longer yields to the launch stream (the eager
-// two-stream step then takes 32-35 ms instead of 28.9, profiles/r03_experiments.md).  ops.autotune_wgrad_side_stream() times the step
-// and asks for another stream when the first one loses.  The old stream is drained and left alive (captured graphs may name it).
+// Drop the side stream for a fresh one.  How a HIP stream maps onto the hardware queues is the runtime's choice at creation; on some
+// boxes / processes the low-priority stream lands where it no longer yields to the launch stream (the eager two-stream step then takes
+// 32-35 ms instead of 28.9, profiles/r03_experiments.md).  ops.autotune_wgrad_side_stream() times the step and asks for another stream
+// when the first one loses.  The old stream is drained and then DESTROYED -- unless a capture is in progress on it (refused: a captured
+// graph names its streams only while capturing; replays do not use them).  The new stream is created first and swapped in on success.
 extern "C" int fva_side_stream_renew(void) {
     if (!g_side) return FVA_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(g_side, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return fva_fail(FVA_ERR_ARG, "fva_side_stream_renew: the side stream is being captured");
     if (hipStreamSynchronize(g_side) != hipSuccess) return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_renew: synchronize failed");
-    g_side = nullptr;           // events are reused
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess)
-        return fva_fail(FVA_ERR_LAUNCH, "fva_side_stream_renew: cannot create the side stream");
+    hipStream_t s = nullptr;
+    const int rc = side_stream_create(&s, "fva_side_stream_renew");
+    if (rc) return rc;               // the old stream stays in place
+    (void)hipStreamDestroy(g_side);
+    g_side = s;
     return FVA_OK;
 }
 

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ....parallel import refuse_dataparallel_replica
 from .darknet import ConvBlock1x1, ConvBlock3x3, darknet53
 
 __all__ = ['NeckV3', 'HeadV3', 'YoloV3']
@@ -70,4 +71,5 @@ class YoloV3(nn.Module):
         self.head = HeadV3(1024, 512, 256, anchors, num_classes)
 
     def forward(self, x):
+        refuse_dataparallel_replica(self)        # the demo wraps its model in nn.DataParallel (demos/yolov3_u/train.py:85): one visible device only
         return self.head(*self.neck(*self.backbone(x)))

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ...detect_ops import yolo_decode
+from ...parallel import refuse_dataparallel_replica
 
 __all__ = ['Yolov3', 'yolov3']
 
@@ -32,6 +33,7 @@ class Yolov3(nn.Module):
                          num_anchors_per_level=num_anchors_per_level, num_classes=num_classes)
 
     def forward(self, images, val=False):
+        refuse_dataparallel_replica(self)        # nn.DataParallel over > 1 device: one process per GPU instead (parallel.py)
         head_out = self.head(self.neck(self.backbone(images)))
         if self.training and not val:
             return head_out

@@ -51,8 +51,11 @@ class GraphedTrainStep:
         (loss/yolov3_loss.py:98-99: max(r, 1/r) = inf), so the library loss sees exactly the rows the reference would; the demo
         loss assigns EVERY row to its best anchor, so it must be captured with its exact target count (max_targets=None).
     The captured sequence includes the weight re-pack, the weight gradients, BatchNorm running statistics and the optimizer.
-    Results are bit-identical with the eager step (same kernels, same order, same addresses' contents);
-    ``tests/test_gpu_graph.py`` checks that.
+    Results are bit-identical with the eager step issued under the same weight-gradient plan (same kernels, same order, same
+    split-K factors; ``tests/test_gpu_graph.py`` checks that).  The plan (``ops.get_wgrad_plan()``) fixes the fp32 summation order
+    of dW and in its default 'auto' mode follows the side-stream switch: a single-stream capture therefore runs the 'alone' plan and
+    equals the eager SINGLE-stream step bit for bit, while the eager two-stream step ('beside' plan) differs from it in the last bits
+    of dW; ``ops.set_wgrad_plan('alone' | 'beside')`` pins one plan for both.  ``self.wgrad_plan`` records what was captured.
     ``side_stream`` (default False): capture on ONE stream.  A second graph branch for the weight gradients replays at equal
     priority and takes CUs from the critical path -- 43-44 ms instead of 32 per YOLOv3 step (the eager
     step's side stream is low-priority, which graph kernel nodes cannot be on this runtime) -- so the library's side stream is
@@ -93,6 +96,7 @@ class GraphedTrainStep:
                 raise RuntimeError(f'GraphedTrainStep(side_stream=True): a two-branch HIP graph crashes in hipGraphLaunch with GPU_MAX_HW_QUEUES={q} '
                                    '(< 4) on ROCm 7.2; capture single-stream (the default) or allow at least 4 hardware queues')
         side_was = ops.set_wgrad_side_stream(bool(side_stream) and ops._SIDE['on'])
+        self.wgrad_plan = ops.get_wgrad_plan()
         try:
             snap = self._snapshot()
             side = torch.cuda.Stream()

@@ -59,31 +59,6 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-_conv_ws = {}
-
-
-def ensure_conv_workspace(device, force=False):
-    """Register (once per process) the stream-K scratch of the 256x256 conv kernel: a zero-filled device buffer this module
-    keeps alive.  Only when the FVA_STREAMK experiment is switched on (it is slower at B = 32: conv_igemm.hip streamk_mode).
-    One GPU per process (the data-parallel design)."""
-    if _conv_ws:
-        return
-    import os
-    if not force and os.environ.get('FVA_STREAMK', '0') in ('', '0'):
-        _conv_ws[None] = None
-        return
-    lib = _lib.load()
-    nbytes = lib.fva_conv_workspace_bytes()
-    if nbytes > 0:
-        with torch.cuda.device(device):
-            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-            torch.cuda.current_stream(device).synchronize()
-            _lib.call('fva_conv_set_workspace', _p(buf), nbytes)
-        _conv_ws[torch.device(device)] = buf
-    else:
-        _conv_ws[None] = None
-
-
 def require_gpu(t, who):
     if not t.is_cuda:
         raise RuntimeError(f'fastvision_amd.{who}: tensors must live on the GPU -- this package has no CPU path '
@@ -261,37 +236,6 @@ def set_bn_backward_fusion(on):
     return prev
 
 
-# ---- BatchNorm finalisation inside the producing launch (csrc/bn_ticket.h) -----------------------------------------------------
-# The waves that write a partial-statistics table draw tickets; the last arriver folds and finalises: no bn_finalize /
-# bn_bwd_finalize / bn_prereduce launch (197 per YOLOv3 step).  Built in round 3 and MEASURED SLOWER than the launches it removes
-# (profiles/r03_ticket_tail.md: the fold is a chain of dependent memory round trips -- drain, ticket, rows, drain, ticket, groups --
-# at the very end of the producing launch, 6-36 us per layer against 4-11 us for the stand-alone finalize launch, whose cost in a
-# back-to-back chain turned out to be 0.95 ms per step, not the 2.0 ms of summed kernel durations), so it is OFF by default
-# (env FVA_BN_TICKET=1 / set_bn_ticket_finalize(True) turn it on; tests/test_gpu_bn_ticket.py keeps it correct).  The ticket
-# counters live on the BatchNorm weight (zero-filled once; every launch leaves them zero), one set per direction.
-_BN_TICKET = [os.environ.get('FVA_BN_TICKET', '0') != '0']
-
-
-def set_bn_ticket_finalize(on):
-    """Switch the in-launch BatchNorm finalisation on or off (default off; env FVA_BN_TICKET=1).  Returns the previous setting."""
-    prev = _BN_TICKET[0]
-    _BN_TICKET[0] = bool(on)
-    return prev
-
-
-def _ticket_scratch(gamma, tag, rows, Cc):
-    """(counters, group_sums) for a table of ``rows`` rows of ``Cc`` channels; the counters persist on ``gamma``."""
-    lib = _lib.load()
-    key = (rows, Cc, gamma.device)
-    hit = getattr(gamma, tag, None)
-    if hit is None or hit[0] != key:
-        hit = (key, torch.zeros(lib.fva_bn_ticket_counters(rows, Cc), dtype=torch.int32, device=gamma.device))
-        setattr(gamma, tag, hit)
-    ng = lib.fva_bn_ticket_groups(rows)
-    gs = torch.empty((ng, 2, Cc), dtype=torch.float64, device=gamma.device) if ng > 1 else None
-    return hit[1], gs
-
-
 def _note_consumer(x):
     """A consumer of x that will hand back a gradient: called by every autograd node of this module in forward."""
     src = getattr(x, '_fva_prod', None)
@@ -310,24 +254,11 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
     if (_BN_FUSE[0] and src is not None and src.consumers == 1 and src.training and src.dtype == dtype
             and src.M == d.B * d.H * d.W and src.d.Cout == d.Cin and not torch.is_grad_enabled()):
         rows = _lib.load().fva_conv_dgrad_stat_rows(C.byref(d))
-        if rows > 0 and _BN_TICKET[0] and d.Cin % 32 == 0:
-            # ... and the finalisation too: dgamma / dbeta / the pass-2 coefficients of the producer leave this launch
-            part = torch.empty((rows, 2, d.Cin), dtype=torch.float32, device=dx.device)
-            fs = _fuse_struct(src, part)
-            cnt, gs = _ticket_scratch(src.gamma, '_fva_tk_bwd', rows, d.Cin)
-            dgamma = torch.empty(d.Cin, dtype=torch.float32, device=dx.device)
-            dbeta = torch.empty_like(dgamma)
-            coef = torch.empty((3, d.Cin), dtype=torch.float32, device=dx.device)
-            fin = _lib.BnBwdFin(cnt.data_ptr(), gs.data_ptr() if gs is not None else None, src.gamma.data_ptr(), dgamma.data_ptr(),
-                                dbeta.data_ptr(), coef.data_ptr(), 0)
-            _lib.call('fva_conv_dgrad_bn', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), C.byref(fin), _stream())
-            src.fused = (part, rows, dx.data_ptr(), dx, (dgamma, dbeta, coef), gs)
-            return
         if rows > 0:
             part = torch.empty((_lib.load().fva_bn_partial_rows(rows), 2, d.Cin), dtype=torch.float32, device=dx.device)
             fs = _fuse_struct(src, part)
             _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
-            src.fused = (part, rows, dx.data_ptr(), dx, None, None)
+            src.fused = (part, rows, dx.data_ptr(), dx)
             return
     _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
 
@@ -338,8 +269,6 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     B, Cin, H, W = x.shape
     Cout, _, k, _ = weight.shape
     lib = _lib.load()
-    if not _conv_ws:
-        ensure_conv_workspace(x.device)
     x_src = _note_consumer(x) if need_ctx else None
     d = ConvDesc(_code(dtype), B, H, W, Cin, Cout, k, stride, x_pad, 1)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -370,26 +299,16 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
-        if _BN_TICKET[0] and Cout % 32 == 0:
-            stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=dev)
-            cnt, gs = _ticket_scratch(gamma, '_fva_tk_fwd', nblk, Cout)
-            fin = _lib.BnFwdFin(cnt.data_ptr(), gs.data_ptr() if gs is not None else None, gamma.data_ptr(), beta.data_ptr(),
-                                bn.rm.data_ptr(), bn.rv.data_ptr(), bn.nbt.data_ptr(), bn.momentum, bn.eps, mean.data_ptr(),
-                                rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
-            _lib.call('fva_conv_fwd_bn', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), C.byref(fin), _stream())
-            del gs          # stream-ordered allocator: the apply pass that follows is enqueued behind the launch that uses it
-        else:
-            stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
-            _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
-            _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
-                      bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+        stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+        _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                  bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
     else:
         _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), C.c_void_p(0), _stream())
         _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
     zbuf, z = halo_alloc(B, Cout, OH, OW, dtype, dev, 1)
     rp, rpad = (C.c_void_p(residual[0]), residual[1]) if residual is not None else (C.c_void_p(0), 0)
-    if not _ABLATE['apply']:
-        _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
+    _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
     s = None
     if need_ctx:
         s = _Saved()
@@ -411,6 +330,35 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
 # callback queued on the autograd engine performs at the end of the backward pass (anything that reads .grad earlier -- the
 # gradient-bucket hooks of parallel.GradientReducer -- joins first through join_side_stream()).
 _SIDE = {'on': os.environ.get('FVA_WGRAD_STREAM', '1') != '0', 'keep': [], 'queued': False, 'torch': None}
+
+# The split-K plan of the weight gradients (fva_conv_wgrad_plan) fixes the fp32 summation order of dW.  It is a process-wide, sticky
+# setting: 'auto' (default) follows the side-stream switch -- 'beside' while the weight gradients run on the side stream, 'alone'
+# otherwise --, 'alone' / 'beside' pin it.  It never depends on which stream an individual launch is given, so a layer that falls back
+# to the launch stream (gradient accumulation) sums in the same order as its neighbours, and two runs under the same plan are
+# bit-identical whether they are issued eagerly on two streams or replayed from a single-stream graph.
+_PLAN = {'mode': os.environ.get('FVA_WGRAD_PLAN', 'auto'), 'applied': None}
+
+
+def _apply_wgrad_plan():
+    want = 1 if (_PLAN['mode'] == 'beside' or (_PLAN['mode'] == 'auto' and _SIDE['on'])) else 0
+    if _PLAN['applied'] != want:
+        _lib.call('fva_conv_wgrad_plan', want)
+        _PLAN['applied'] = want
+
+
+def set_wgrad_plan(mode):
+    """'auto' | 'alone' | 'beside' (see above).  Returns the previous mode."""
+    if mode not in ('auto', 'alone', 'beside'):
+        raise ValueError("wgrad plan must be 'auto', 'alone' or 'beside'")
+    prev, _PLAN['mode'] = _PLAN['mode'], mode
+    _apply_wgrad_plan()
+    return prev
+
+
+def get_wgrad_plan():
+    """The plan in force: 'alone' or 'beside' (what the bench line records as config.wgrad_plan)."""
+    _apply_wgrad_plan()
+    return 'beside' if _PLAN['applied'] else 'alone'
 
 
 def join_side_stream(force=False):
@@ -441,6 +389,7 @@ def set_wgrad_side_stream(on):
     if prev and not on:
         join_side_stream(force=True)
     _SIDE['on'] = bool(on)
+    _apply_wgrad_plan()
     return prev
 
 
@@ -501,6 +450,8 @@ def wgrad_stream(buffers, weight=None):
     """Stream argument for a weight-gradient launch (called from inside a backward pass).  A parameter that already holds a
     gradient (accumulation over micro-batches) gets its dW added by autograd on the main stream right after this backward
     returns, so that layer stays on the main stream; so does everything under create_graph."""
+    if _PLAN['applied'] is None:
+        _apply_wgrad_plan()
     if not _SIDE['on'] or torch.is_grad_enabled() or (weight is not None and (not weight.is_leaf or weight.grad is not None)):
         return _stream()          # (a derived weight, e.g. a channel-padded filter: autograd's next node reads dW on the main stream)
     side = C.c_void_p()
@@ -508,6 +459,7 @@ def wgrad_stream(buffers, weight=None):
         _lib.call('fva_side_stream_fork', _stream(), C.byref(side))
     except RuntimeError:                          # e.g. a second device in this process: everything stays on the launch stream
         _SIDE['on'] = False
+        _apply_wgrad_plan()
         return _stream()
     _SIDE['keep'].append(buffers)
     # one callback per launch, not one per backward pass: a pass that dies with an exception never runs its callbacks, and a
@@ -520,10 +472,6 @@ def wgrad_stream(buffers, weight=None):
     return side
 
 
-# timing experiments only (results wrong): FVA_ABLATE=wgrad,apply,... skips those launches to see what they cost the step
-_ABLATE = {k: k in os.environ.get('FVA_ABLATE', '').split(',') for k in ('wgrad', 'apply', 'bwd_apply', 'dgrad')}
-
-
 def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     """Backward of conv_block_fwd given dz (dense NHWC, dtype).  Returns (dx_buf or None, dw, dgamma, dbeta)."""
     if not s.training:
@@ -532,36 +480,29 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     d, dtype, dev = s.d, s.dtype, s.y.device
     Cout, code = d.Cout, _code(s.dtype)
     fused, s.fused = s.fused, None
-    done = None
     if fused is not None and fused[2] == dz_ptr:
-        part, nb, done = fused[0], fused[1], fused[4]   # the consumer's dgrad epilogue has already summed dU and dU * xhat
+        part, nb = fused[0], fused[1]                   # the consumer's dgrad epilogue has already summed dU and dU * xhat
     else:
         nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
         part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
                   _p(part), nb, s.M, Cout, _stream())
     del fused
-    if done is not None:
-        dgamma, dbeta, coef = done                      # ... and finalised them in the same launch (bn_ticket.h)
-    else:
-        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-        dbeta = torch.empty_like(dgamma)
-        coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-        _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+    _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
     dy = torch.empty((d.B, s.OH + 2, s.OW + 2, Cout), dtype=dtype, device=dev)
-    if not _ABLATE['bwd_apply']:
-        _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-                  _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+    _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+              _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    if not _ABLATE['wgrad']:
-        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, wgrad_stream((s.x, getattr(s, 'keep', None), dy, ws), s.weight))     # NOT dw: a second reference makes AccumulateGrad clone it (on the main stream)
+    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(s.x_ptr), _p(dy), _p(dw), 0, _p(ws), ws_bytes, wgrad_stream((s.x, getattr(s, 'keep', None), dy, ws), s.weight))     # NOT dw: a second reference makes AccumulateGrad clone it (on the main stream)
     dx = None
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
-        if not _ABLATE['dgrad']:
-            _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
+        _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
     return dx, dw, dgamma, dbeta
 
 

@@ -28,7 +28,7 @@ import contextlib
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'GradientReducer', 'broadcast_parameters', 'shard_targets']
+__all__ = ['init_from_env', 'GradientReducer', 'broadcast_parameters', 'shard_targets', 'refuse_dataparallel_replica']
 
 
 def init_from_env(backend=None):
@@ -68,6 +68,21 @@ def broadcast_parameters(module, src=0, group=None):
             off += t.numel()
 
 
+def refuse_dataparallel_replica(module):
+    """Called at the top of the detection models' forward.  The reference wraps its model in ``nn.DataParallel``
+    (demos/yolov3_u/train.py:85, generate/template-yolov3/train.py:81-83).  With ONE visible device that wrapper calls the module
+    directly and everything works; with more it replicates the module onto the other devices every step and runs the replicas from
+    threads -- but this package's kernels, side stream, packed-weight caches and BatchNorm buffers are per process and per device (one
+    process per GPU is the model, SURVEY 8b: "refuse DP-wrap and provide its own DP").  A replica (``_is_replica``, set by
+    nn.Module._replicate_for_data_parallel) therefore refuses loudly instead of computing on state it does not own."""
+    if getattr(module, '_is_replica', False):
+        raise RuntimeError(
+            'fastvision_amd: nn.DataParallel over more than one device is not supported -- the HIP kernels, the weight-gradient side '
+            'stream and the packed-weight caches are per process and per device.  Run one process per GPU instead (python -m '
+            'torch.distributed.run --nproc-per-node N ...; fastvision_amd.parallel.init_from_env() + GradientReducer; for the library '
+            'loss also Yolov3Loss.data_parallel()), or make one device visible (HIP_VISIBLE_DEVICES=0): INTEGRATION.md section 1.')
+
+
 def shard_targets(targets, rank, per_rank_batch):
     """Rows of a global [T,6] target table that belong to this rank's images, re-based to local image indices."""
     lo = rank * per_rank_batch
@@ -95,10 +110,19 @@ class GradientReducer:
     ``bucket_dtype``: dtype the gradients travel in (default: the parameters' own, fp32 -- what the reference's DataParallel
     reduces).  torch.bfloat16 halves the bytes on the xGMI links (124 MB instead of 248 MB per step for YOLOv3); finish() widens the
     reduced wire buffers back into the fp32 buckets that ``p.grad`` views, so the optimizer always reads fp32.
-    ``stats()`` reports what the last step did (backend, world size, buckets launched before backward ended, bytes on the wire).
+    ``late``: how many buckets behind its fill a bucket's all-reduce is issued from the main stream (default 1).  The main stream
+    waits for the fill event, which is recorded on the low-priority side stream; issued one bucket late that event is normally long
+    past.  Where the side stream lags further (its own hardware queue: DESIGN.md section 6, wait (4)) the main stream stalls there --
+    ``stats()['main_stream_wait_ms']`` measures exactly that, per step, from timing events around the wait -- and ``late=2`` trades it
+    for a longer tail in ``finish()``.
+    ``stats()`` reports what the last step did (backend, world size, buckets launched before backward ended, bytes on the wire, and
+    how long the main stream sat waiting for fill events).
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True, bucket_dtype=None, world=None):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, average=True, bucket_dtype=None, world=None, late=1):
+        if late not in (1, 2):
+            raise ValueError('GradientReducer: late must be 1 or 2')
+        self.late = late
         self.group, self.average, self.bucket_dtype = group, average, bucket_dtype
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)   # world: tests only
         if self.world == 1:
@@ -122,7 +146,8 @@ class GradientReducer:
         self.filled = 0               # GPU buckets: filled up to here (their collectives follow one bucket later)
         self._gpu = {}
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self.last = {'launched_in_backward': 0, 'collectives': 0}
+        self.last = {'launched_in_backward': 0, 'collectives': 0, 'waits': []}
+        self._waits = []              # (event before the main stream's wait, the fill event): this step's, timed in stats()
         self.reset()
 
     def stats(self):
@@ -136,7 +161,22 @@ class GradientReducer:
                 'collectives_per_step': self.last['collectives'],
                 'wire_dtype': str(self.buckets[0][3].dtype).replace('torch.', '') if self.buckets else None,
                 'wire_bytes_per_step': sum(b[3].numel() * b[3].element_size() for b in self.buckets) if self.world > 1 else 0,
-                'reduce_op': 'avg' if self.average else 'sum'}
+                'reduce_op': 'avg' if self.average else 'sum', 'late': self.late,
+                'main_stream_wait_ms': self._wait_ms(self.last.get('waits', []))}
+
+    @staticmethod
+    def _wait_ms(pairs):
+        """Time the main stream spent in wait_event(filled) over one step: for every bucket, fill time minus the time the main
+        stream reached the wait, where positive (both are timing events; synchronises on them -- call outside a timed region)."""
+        total = 0.0
+        for pre, filled in pairs:
+            try:
+                pre.synchronize()
+                filled.synchronize()
+                total += max(0.0, pre.elapsed_time(filled))
+            except RuntimeError:
+                return None
+        return round(total, 3)
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
@@ -186,7 +226,8 @@ class GradientReducer:
             static = [p.numel() for p in plist] + offs
             st = self._gpu[bi] = {'n': n, 'key': None, 'flip': 0, 'max': max(p.numel() for p in plist),
                                   'pinned': [torch.zeros(3 * n, dtype=torch.int64).pin_memory() for _ in range(2)],
-                                  'event': [torch.cuda.Event(), torch.cuda.Event()], 'used': [False, False], 'filled': torch.cuda.Event(),
+                                  'event': [torch.cuda.Event(), torch.cuda.Event()], 'used': [False, False],
+                                  'filled': torch.cuda.Event(enable_timing=True), 'pre': torch.cuda.Event(enable_timing=True),
                                   'table': torch.zeros(3 * n, dtype=torch.int64, device=flat.device)}
             for h in st['pinned']:
                 h[n:] = torch.tensor(static, dtype=torch.int64)
@@ -241,7 +282,11 @@ class GradientReducer:
         main stream's kernels.  Measured on one MI355X with a one-rank RCCL group: 43.8 ms per step instead of 31.4 (44 / 34 / 31 ms
         with GPU_MAX_HW_QUEUES = 4 / 8 / 2: pure queue aliasing).  A barrier that waits for the MAIN stream's recent past is harmless
         wherever it lands."""
-        torch.cuda.current_stream(self.buckets[bi][0].device).wait_event(self._gpu[bi]['filled'])
+        cur = torch.cuda.current_stream(self.buckets[bi][0].device)
+        st = self._gpu[bi]
+        st['pre'].record(cur)                         # when the main stream reaches the wait
+        cur.wait_event(st['filled'])
+        self._waits.append((st['pre'], st['filled']))
         self._launch(bi)
 
     def _on_grad(self, p):
@@ -253,7 +298,7 @@ class GradientReducer:
                 self.filled += 1
             # a bucket's collective goes out one bucket late: by then the side stream has (almost always) passed its fill, and
             # the main stream's wait for it costs nothing
-            while self.next_launch < self.filled - 1:
+            while self.next_launch < self.filled - self.late:
                 self._launch_gpu(self.next_launch)
                 self.next_launch += 1
             return
@@ -288,7 +333,7 @@ class GradientReducer:
     def finish(self):
         """Launch what is still outstanding (parameters that received no gradient contribute zeros), wait for every
         collective and re-arm for the next step."""
-        self.last = {'launched_in_backward': self.next_launch, 'collectives': 0}
+        self.last = {'launched_in_backward': self.next_launch, 'collectives': 0, 'waits': []}
         if self.params and self.params[0].is_cuda:
             from .ops import join_side_stream
             join_side_stream(force=True)
@@ -317,6 +362,7 @@ class GradientReducer:
                     wire.div_(self.world)
                 if wire.data_ptr() != flat.data_ptr():
                     flat.copy_(wire)
+        self.last['waits'], self._waits = self._waits, []
         self.reset()
 
     def remove(self):

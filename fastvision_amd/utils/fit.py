@@ -12,7 +12,7 @@ from ..detection.tools import non_max_suppression_images, xywh2xyxy
 from ..metrics import CalculateMAP
 from .checkpoints import SaveModel
 
-__all__ = ['Fit']
+__all__ = ['Fit', 'stall_watch']
 
 
 def _freeze_garbage_collector():
@@ -22,6 +22,32 @@ def _freeze_garbage_collector():
     import gc
     gc.collect()
     gc.freeze()
+
+
+class stall_watch:
+    """A rare host stall is on record (4 of ~120 eager benchmark runs of rounds 2 and 3: the HOST stopped issuing launches for
+    180-770 ms inside one step, cause unknown, the GPU ran dry).  Re-running does not find such a thing; naming the blocking call when
+    it next happens does: around every training step a watchdog (faulthandler's own thread: no cost while nothing hangs) dumps every
+    thread's Python stack to stderr once when the step has not returned after ``seconds``.  bench.py arms the same watchdog in its
+    timed loop.  FVA_STALL_WATCH=0 switches it off; FVA_STALL_WATCH=<seconds> changes the threshold (default 0.5 s here: a step may
+    legitimately wait for its data loader)."""
+
+    def __init__(self, seconds=None):
+        import os
+        env = os.environ.get('FVA_STALL_WATCH')
+        self.seconds = float(env) if env not in (None, '') else (0.5 if seconds is None else seconds)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import faulthandler
+            import sys
+            faulthandler.dump_traceback_later(self.seconds, repeat=False, file=sys.stderr, exit=False)
+        return self
+
+    def __exit__(self, *a):
+        if self.seconds > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
 
 
 class Fit:
@@ -57,11 +83,12 @@ class Fit:
         losses = []
         for batch_idx, (images, labels) in enumerate(self.train_loader):
             images, labels = self._to_device(images, labels)
-            pred = self.model(images)
-            self.optimizer.zero_grad()
-            loss = self.loss(pred, labels)
-            loss.backward()
-            self.optimizer.step()
+            with stall_watch():
+                pred = self.model(images)
+                self.optimizer.zero_grad()
+                loss = self.loss(pred, labels)
+                loss.backward()
+                self.optimizer.step()
             losses.append(loss.detach())          # device tensor: no per-step host sync (the reference's tqdm .item() does one)
             if epoch == self.start_epoch and batch_idx == 0:
                 _freeze_garbage_collector()

@@ -102,14 +102,10 @@ int fva_conv_pack_weights_multi(const fva_pack_entry* table, int32_t n, int64_t 
  * entry): no idle blocks for small layers, 16-byte loads and 8-byte stores on aligned bf16 tiles. */
 int fva_conv_pack_weights_tiled(const fva_pack_entry* table, int32_t n, int32_t total_tiles, void* stream);
 
-/* Optional scratch for the EXPERIMENTAL stream-K form of the 256x256 MFMA kernel (env FVA_STREAMK=1; measured slower than
- * whole tiles at B = 32, off by default): one 256-KiB accumulator slab per CU + flags.  The caller owns the buffer, zero-fills it once,
- * registers it once per process (one GPU per process) and keeps it alive; conv launches that use it must not overlap
- * each other (they are issued on one stream).  Without it those layers run whole tiles per block.
- * fva_conv_streamk_timeouts() (diagnostic, synchronises): polls that gave up -- must stay 0. */
-int64_t fva_conv_workspace_bytes(void);
-int fva_conv_set_workspace(void* workspace, int64_t bytes);
-int64_t fva_conv_streamk_timeouts(void);
+/* Which MFMA kernel the calling thread's last convolution entry point launched: "igemm8" (256x256 8-phase), "igemm128", "igemm256x64",
+ * "pconv", "pdgrad2" (patch kernels); "wgrad8", "wgrad128", "wgrad128thin", "wgrad64f32", "pwgrad".  For tests that must know what they compared. */
+const char* fva_conv_last_kernel(void);
+
 /* Diagnostic: while set (non-NULL), every block of an 8-phase convolution launch writes eight values to stamps[block * 8 ..]:
  * wall_clock64 (100 MHz) at block entry, first k-tile ready, k-loop done and exit, then the shader-clock cycle counter at the
  * same four points (cycles / wall time = the shader clock under load).  `rows` = capacity of the buffer in blocks (8 values
@@ -127,28 +123,6 @@ int fva_conv_patch_kernel(int on);
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
  * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
-/* The same with the BatchNorm finalisation INSIDE the launch (round 3; csrc/bn_ticket.h): the waves that write the partial table
- * draw tickets, the last arriver of each group of rows folds that group in row order (double), the last group folds the groups and
- * writes what fva_bn_finalize writes -- batch mean / rstd, scale = gamma*rstd, shift = beta - mean*scale, the running statistics
- * (momentum, unbiased variance) and num_batches_tracked += 1 (classfication/models/darknet53.py:11-12: nn.BatchNorm2d in training
- * mode).  No second launch; fixed summation order, so results are bit-identical from launch to launch.  Needs Cout % 32 == 0.
- *   counters:   fva_bn_ticket_counters(fva_conv_stat_blocks(d), Cout) int32, ZERO before the first use; every launch leaves them
- *               zero again (do not share them between launches that may overlap);
- *   group_sums: fva_bn_ticket_groups(fva_conv_stat_blocks(d)) x [2][Cout] doubles of scratch (may be NULL for one group);
- *   stats_partial: plain fva_conv_stat_blocks(d) rows of [2][Cout] floats (no fva_bn_partial_rows() tail needed). */
-typedef struct {
-    int32_t* counters;
-    double* group_sums;
-    const float *gamma, *beta;
-    float *running_mean, *running_var;      /* may be NULL */
-    int64_t* num_batches_tracked;           /* may be NULL */
-    float momentum, eps;
-    float *save_mean, *save_rstd, *scale, *shift;
-} fva_bn_fwd_fin;
-int fva_conv_fwd_bn(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, const fva_bn_fwd_fin* fin,
-                    void* stream);
-int32_t fva_bn_ticket_groups(int32_t rows);
-int64_t fva_bn_ticket_counters(int32_t rows, int32_t C);
 /* Inference form: eval-mode BatchNorm folded into a per-channel affine and SiLU applied in the convolution's epilogue,
  * z = SiLU(conv(x) * scale[c] + shift[c]) (+ residual), written straight into the halo buffer z [B][OH+2p][OW+2p][Cout]
  * (interior by the MFMA kernel, zero border by a small second launch).  residual (optional) has z's geometry.
@@ -167,7 +141,7 @@ int fva_conv_dgrad(const fva_conv_desc* d, const void* dy, const void* w_dgrad, 
  * 58-62: what autograd's native_batch_norm_backward + SiLU backward reduce over the batch): per row block and channel the
  * epilogue adds up dU = dz * SiLU'(y * scale + shift) and dU * (y - mean) * rstd from the values it stores, reading y (dense
  * [B*H*W][Cin], the producer's pre-BN output) once.  partial: [fva_bn_partial_rows(fva_conv_dgrad_stat_rows(d))][2][Cin] floats (the rows
- * beyond fva_conv_dgrad_stat_rows(d) are fva_bn_bwd_finalize's scratch), write-through stores, fixed order -- feed it to
+ * beyond fva_conv_dgrad_stat_rows(d) are fva_bn_bwd_finalize's scratch), fixed order -- feed it to
  * fva_bn_bwd_finalize (partial_rows = the rows allocated) in place of fva_bn_silu_bwd_reduce's table.  Valid only when dx IS the whole dz (the
  * producer's output has no other consumer than this convolution and, through `addend`, the residual identity). */
 typedef struct {
@@ -178,25 +152,18 @@ typedef struct {
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* fuse, void* stream);
 int32_t fva_conv_dgrad_stat_rows(const fva_conv_desc* d);
-/* ... and with the producer's BatchNorm-backward finalisation inside the same launch(es) (tickets as in fva_conv_fwd_bn; the parity
- * launches of a stride-2 layer share one table and one set of counters): writes what fva_bn_bwd_finalize writes -- dgamma, dbeta
- * (+= when accumulate) and coef[3][Cin] for fva_bn_silu_bwd_apply.  Needs Cin % 32 == 0.  counters / group_sums are sized with
- * rows = fva_conv_dgrad_stat_rows(d), C = Cin; fuse->partial then needs only those rows.  fin == NULL: fva_conv_dgrad_bnstats. */
-typedef struct {
-    int32_t* counters;
-    double* group_sums;
-    const float* gamma;                     /* of the producer's BatchNorm; its rstd is fuse->rstd */
-    float *dgamma, *dbeta, *coef;
-    int32_t accumulate;
-} fva_bn_bwd_fin;
-int fva_conv_dgrad_bn(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
-                      const fva_bn_bwd_fuse* fuse, const fva_bn_bwd_fin* fin, void* stream);
 
 /* dw (fp32, OIHW) (+)= sum_pixels dy x.  Deterministic: split-K partial tiles go to `workspace`
  * (fva_conv_wgrad_workspace() bytes) and are reduced in fixed order. */
 int fva_conv_wgrad(const fva_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t fva_conv_wgrad_workspace(const fva_conv_desc* d);
+/* The split-K plan of the weight gradients, process-wide: 0 = for a launch that has the chip to itself (default), 1 = for launches
+ * that run beside the rest of the backward pass on the side stream (half the block slots: fewer, longer blocks).  The plan fixes
+ * the split factor and with it the fp32 summation order of dW: results are bit-identical between runs under the SAME plan, and
+ * differ in the last bits between plans.  Returns the previous setting; any other argument only queries.  The workspace size
+ * covers both. */
+int fva_conv_wgrad_plan(int beside);
 
 /* Stem: conv 3x3 s1 p1 on fp32 NCHW images with Cin <= 3, Cout == 32 (darknet53.py:73 `conv0`).
  * y dense [B*H*W][Cout] dtype + BN partial stats;  wgrad from dy dense [B*H*W][Cout] (pad 0).

@@ -161,7 +161,7 @@ def test_training_step_same_with_and_without_fused_statistics(key, surface):
     worst = devs.max()
     n_bn = n0['fva_bn_silu_bwd_reduce']
     left = n1.get('fva_bn_silu_bwd_reduce', 0)
-    print(f'{surface} {key}: stand-alone reduce launches {n_bn} -> {left}, fused dgrad launches {n1.get("fva_conv_dgrad_bnstats", 0) + n1.get("fva_conv_dgrad_bn", 0)}, '
+    print(f'{surface} {key}: stand-alone reduce launches {n_bn} -> {left}, fused dgrad launches {n1.get("fva_conv_dgrad_bnstats", 0)}, '
           f'gradient deviation (max-abs over the tensor scale): median {np.median(devs):.2e}, largest {worst:.2e}')
     # fp32: the two paths differ by the summation order of the statistics only.  bf16: that last-bit difference of a coefficient
     # flips bf16 roundings of dY, and 70 layers of backward amplify it to the noise level of the dtype itself (the bf16 step

@@ -517,3 +517,141 @@ def test_patch_kernel_against_the_implicit_gemm_kernels(case):
         assert ((a - b).abs().mean() / b.abs().mean()).item() < 2e-3, what
     assert torch.equal(dx1, dxb1)
     assert rel_err(s1, s0) < 1e-4 and rel_err(p1, p0) < 2e-3
+
+
+# ---- the kernels the BENCHMARK dispatches, element by element against a non-HIP reference (round 4) -------------------------------
+# CONV_CASES above are small: they exercise igemm_kernel (128 x 128 / 256 x 64), the patch kernels and pwgrad_kernel, but the 8-phase
+# kernels (igemm8_kernel, wgrad8_kernel) only dispatch from 128 tiles of 256 x 256 on and were compared with other HIP kernels only.
+# Here shapes that select them run through the C ABI against ATen's fp32 convolutions on the CPU fed the same bf16-rounded operands,
+# 1e-2 of the tensor scale as above, and the library says which kernel ran (fva_conv_last_kernel).
+BIG_CASES = [
+    # B, Cin, Cout, H, k, stride,  forward,   dgrad,      wgrad
+    (32, 128, 256, 80, 3, 1, 'igemm8', 'igemm128', 'wgrad8'),      # 800 tiles; dgrad N = 128 stays on the 128 x 128 kernel; wgrad: Cin = 128, two taps per column tile
+    (12, 512, 1024, 40, 3, 1, 'igemm8', 'igemm8', 'wgrad8'),       # 72 k-tiles forward, 144 dgrad; ragged last row block (19200 = 75 x 256)
+    (32, 256, 512, 80, 3, 2, 'igemm8', 'igemm8', 'wgrad8'),        # stride 2: forward gathers every other pixel, dgrad = four parity launches
+    (7, 256, 512, 72, 3, 1, 'igemm8', 'igemm8', 'wgrad8'),         # M = 36288: not a multiple of 256 (row tail in the 8-phase epilogue and in wgrad's last k-step)
+    (32, 256, 128, 80, 1, 1, 'igemm128', 'igemm128', 'wgrad128'),  # the residual blocks' 1x1 at its benchmark size (two k-tiles: below the 8-phase kernel's floor)
+]
+
+
+def _kernel():
+    from fastvision_amd import _lib
+    return _lib.load().fva_conv_last_kernel().decode()
+
+
+@pytest.mark.parametrize('case', BIG_CASES)
+def test_benchmark_kernels_elementwise_vs_aten(case):
+    from fastvision_amd import _lib, ops
+    B, Cin, Cout, H, k, s, k_fwd, k_dgrad, k_wgrad = case
+    W = H
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    gy = torch.randn(B, Cout, OH, OW, generator=g)
+    xr, wr, gyr = rounded(x, 'bf16'), rounded(w, 'bf16'), rounded(gy, 'bf16')
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    want_y = F.conv2d(xr, wr, stride=s, padding=k // 2)
+    want_dx = torch.nn.grad.conv2d_input(x.shape, wr, gyr, stride=s, padding=k // 2)
+    want_dw = torch.nn.grad.conv2d_weight(xr, w.shape, gyr, stride=s, padding=k // 2)
+
+    lib = _lib.load()
+    keep, xptr, xpad = halo(x, dtype)
+    d = _lib.ConvDesc(ops._code(dtype), B, H, W, Cin, Cout, k, s, xpad, 1)
+    wf, wd = ops.packed_weights(w.to(dev()), d, dtype, cache=False)
+    M = B * OH * OW
+    y = torch.empty((M, Cout), dtype=dtype, device=dev())
+    nblk = lib.fva_conv_stat_blocks(C.byref(d))
+    stats = torch.full((lib.fva_bn_partial_rows(nblk), 2, Cout), float('nan'), device=dev())
+    _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(xptr), ops._p(wf), ops._p(y), ops._p(stats), ops._stream())
+    ran = {'fwd': _kernel()}
+    got_y = y.float().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    e_y = rel_err(got_y, want_y)
+    ref = want_y.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert torch.allclose(stats[:nblk, 0].sum(0).cpu(), ref.sum(0), rtol=2e-3, atol=2e-3 * (ref ** 2).sum(0).max().sqrt().item())
+    assert torch.allclose(stats[:nblk, 1].sum(0).cpu(), (ref ** 2).sum(0), rtol=2e-3)
+
+    dyk, dyptr, dypad = halo(gy, dtype)
+    dx = torch.empty((B, H, W, Cin), dtype=dtype, device=dev())
+    _lib.call('fva_conv_dgrad', C.byref(d), C.c_void_p(dyptr), ops._p(wd), ops._p(dx), C.c_void_p(0), ops._stream())
+    ran['dgrad'] = _kernel()
+    e_dx = rel_err(dx.float().permute(0, 3, 1, 2), want_dx)
+
+    # the same data gradient with the fused BatchNorm-backward statistics of a producer block (fva_conv_dgrad_bnstats): dx must not
+    # change by a bit, and the two sums must equal what the formulas give on the STORED (bf16) dx and the producer's y
+    yp = torch.randn(B * H * W, Cin, generator=g).to(dev()).to(dtype)
+    sc, sh, mu, rs = [(torch.rand(Cin, generator=g) + 0.5).to(dev()) for _ in range(4)]
+    rows = lib.fva_conv_dgrad_stat_rows(C.byref(d))
+    assert rows > 0
+    part = torch.full((lib.fva_bn_partial_rows(rows), 2, Cin), float('nan'), device=dev())
+    fs = _lib.BnBwdFuse(yp.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), part.data_ptr())
+    dx2 = torch.empty_like(dx)
+    _lib.call('fva_conv_dgrad_bnstats', C.byref(d), C.c_void_p(dyptr), ops._p(wd), ops._p(dx2), C.c_void_p(0), C.byref(fs), ops._stream())
+    ran['dgrad_bnstats'] = _kernel()
+    assert torch.equal(dx2.view(torch.int16), dx.view(torch.int16)), 'the fused-statistics launch changed dx'
+    dzf, yf = dx.float().view(-1, Cin).double(), yp.double()
+    u = yf * sc.double() + sh.double()
+    sg = torch.sigmoid(u)
+    du = dzf * (sg * (1 + u * (1 - sg)))
+    want_s1, want_s2 = du.sum(0), (du * (yf - mu.double()) * rs.double()).sum(0)
+    got = part[:rows].double().sum(0)
+    scale1 = du.abs().sum(0).max().item()
+    assert (got[0] - want_s1).abs().max().item() < 2e-3 * scale1 and (got[1] - want_s2).abs().max().item() < 2e-3 * scale1 * 4
+
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev())
+    wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(xptr), C.c_void_p(dyptr), ops._p(dw), 0, ops._p(ws), wsb, ops._stream())
+    ran['wgrad'] = _kernel()
+    e_dw = rel_err(dw, want_dw)
+    # ... and under the other split-K plan (what the weight gradients use beside the backward pass on the side stream): another
+    # summation order, the same gradient
+    prev = lib.fva_conv_wgrad_plan(1)
+    try:
+        dw_b = torch.empty_like(dw)
+        _lib.call('fva_conv_wgrad', C.byref(d), C.c_void_p(xptr), C.c_void_p(dyptr), ops._p(dw_b), 0, ops._p(ws), wsb, ops._stream())
+    finally:
+        lib.fva_conv_wgrad_plan(prev)
+    e_dw_b = rel_err(dw_b, want_dw)
+    print(f'{case[:6]}: kernels {ran}; max err / scale: y {e_y:.2e}, dx {e_dx:.2e}, dW {e_dw:.2e} (plan "beside" {e_dw_b:.2e}, '
+          f'bit-equal to "alone": {torch.equal(dw, dw_b)})')
+    assert (ran['fwd'], ran['wgrad']) == (k_fwd, k_wgrad), ran
+    assert ran['dgrad'] == k_dgrad and ran['dgrad_bnstats'] == k_dgrad, ran
+    assert e_y < TOL['bf16'] and e_dx < TOL['bf16'] and e_dw < TOL['bf16'] and e_dw_b < TOL['bf16']
+
+
+def test_wgrad_plan_is_a_process_setting_not_a_stream_property():
+    """the split-K plan (and with it the fp32 summation order of dW) used to follow the stream a launch was given.
+    It is now a sticky process-wide setting: the same plan gives the same bits on the launch stream and on the library's side stream."""
+    from fastvision_amd import _lib, ops
+    lib = _lib.load()
+    B, Cin, Cout, H = 32, 128, 256, 80
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H + 2, H + 2, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    dy = torch.randn(B, H + 2, H + 2, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    for t in (x, dy):
+        t[:, 0], t[:, -1], t[:, :, 0], t[:, :, -1] = 0, 0, 0, 0
+    d = _lib.ConvDesc(ops._code(torch.bfloat16), B, H, H, Cin, Cout, 3, 1, 1, 1)
+    wsb = lib.fva_conv_wgrad_workspace(C.byref(d))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    out = {}
+    prev = lib.fva_conv_wgrad_plan(-1)
+    try:
+        for plan in (0, 1):
+            lib.fva_conv_wgrad_plan(plan)
+            for where in ('main', 'side'):
+                dw = torch.empty(Cout, Cin, 3, 3, device=dev())
+                if where == 'side':
+                    side = C.c_void_p()
+                    _lib.call('fva_side_stream_fork', ops._stream(), C.byref(side))
+                    _lib.call('fva_conv_wgrad', C.byref(d), ops._p(x), ops._p(dy), ops._p(dw), 0, ops._p(ws), wsb, side)
+                    _lib.call('fva_side_stream_join', ops._stream())
+                else:
+                    _lib.call('fva_conv_wgrad', C.byref(d), ops._p(x), ops._p(dy), ops._p(dw), 0, ops._p(ws), wsb, ops._stream())
+                torch.cuda.synchronize()
+                out[plan, where] = dw
+    finally:
+        lib.fva_conv_wgrad_plan(prev)
+    assert torch.equal(out[0, 'main'], out[0, 'side']) and torch.equal(out[1, 'main'], out[1, 'side'])
+    assert rel_err(out[0, 'main'], out[1, 'main']) < 1e-5          # two summation orders of one gradient

@@ -166,3 +166,39 @@ def test_bench_starts_its_own_ranks():
     dp = d['dp']            # what the reducer saw: the backend's world size, the wire, one collective per bucket
     assert dp['backend'] == 'gloo' and dp['world_size_seen_by_backend'] == 2 and dp['wire_dtype'] == 'float32' and dp['reduce_op'] == 'sum'
     assert dp['collectives_per_step'] == dp['buckets'] > 1 and dp['wire_bytes_per_step'] == 4 * 61949149
+
+
+def test_dataparallel_replica_refuses_loudly():
+    """The reference wraps its model in nn.DataParallel (demos/yolov3_u/train.py:85).  Over more than one device that wrapper
+    replicates the module (every copy is marked _is_replica by nn.Module._replicate_for_data_parallel) and calls the replicas' forward: both
+    detection models must refuse there with a message that names the supported way, before any kernel is launched."""
+    from fastvision_amd.detection.models.yolov3 import Yolov3
+    from fastvision_amd.demos.yolov3_u.models.yolov3 import YoloV3
+    from fastvision_amd.parallel import refuse_dataparallel_replica
+    from fastvision_amd.synthetic import coco_anchors_feature, coco_anchors_px
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.neck import yolov3neck
+    lib = Yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3], training=True)
+    demo = YoloV3(anchors=tuple(coco_anchors_feature()))
+    for net in (lib, demo):
+        refuse_dataparallel_replica(net)                 # the module itself (one visible device: DataParallel calls it directly) passes
+        net._is_replica = True                           # what torch.nn.parallel.replicate sets on the per-device copies
+        with pytest.raises(RuntimeError, match='one process per GPU'):
+            net(torch.zeros(1, 3, 64, 64))
+    # the signal is torch's own: nn.Module._replicate_for_data_parallel (used by torch.nn.parallel.replicate) marks every copy
+    rep = torch.nn.Linear(2, 2)._replicate_for_data_parallel()
+    assert getattr(rep, '_is_replica', False), 'torch no longer marks replicas: refuse_dataparallel_replica needs another signal'
+
+
+def test_reducer_late_parameter_and_stats_fields():
+    from fastvision_amd import parallel
+    net = torch.nn.Linear(4, 4)
+    with pytest.raises(ValueError):
+        parallel.GradientReducer(net.parameters(), late=3)
+    r = parallel.GradientReducer(net.parameters(), late=2, world=1)
+    net(torch.ones(2, 4)).sum().backward()
+    r.finish()
+    st = r.stats()
+    assert st['late'] == 2 and st['main_stream_wait_ms'] == 0.0      # CPU buckets: no stream, nothing waited
+    r.remove()

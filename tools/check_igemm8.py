@@ -18,8 +18,6 @@ def run(path):
     lib = _lib.load()
     out = {}
     dev = 'cuda:0'
-    if os.environ.get('CHECK_STREAMK', '0') != '0':
-        ops.ensure_conv_workspace(torch.device(dev), force=True)
     dtype = torch.bfloat16
     for si, (B, Cin, Cout, H, k, s) in enumerate(SHAPES):
         g = torch.Generator().manual_seed(si)
@@ -61,7 +59,6 @@ def run(path):
         out[f's{si}_dx'] = dx.float().cpu().numpy().reshape(-1, Cin)[::101, ::3]
         out[f's{si}_dxsum'] = np.array([dx.double().sum().item(), (dx.double() ** 2).sum().item()])
         print(SHAPES[si], 'stat rows', nblk, ' | '.join(f'{k_}: {v[0]:.1f} us {v[1]:.0f} TF' for k_, v in res.items()), flush=True)
-    print('stream-K poll time-outs:', lib.fva_conv_streamk_timeouts())
     np.savez(path, **out)
 
 
