@@ -20,7 +20,7 @@ from fastvision_amd.synthetic import coco_anchors_px, synthetic_batch
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 B, S = 32, 640
-BF16_ELEMENTWISE_GATE = 2.5e-1      # provisional: tightened to 2 x the observed worst value once measured on the GPU (see the assert)
+BF16_ELEMENTWISE_GATE = 4e-1        # observed in round 4: 6e-4 (head bias) ... 2.5e-1 (neck.up1.squeeze, BatchNorm scales); a mis-packed tap or channel reads ~1
 
 # Parameter tensors compared ELEMENT by element with the oracle's gradient (a per-tensor norm survives a permutation of taps or
 # channels inside a kernel's tile packing; max |g - g_ref| / max |g_ref| does not: a permuted tensor reads ~1): the stem, every
@@ -110,6 +110,15 @@ def elementwise_grad_errors(want):
     return {k: ((gpu_step.gsel[k].double() - want[k].double()).abs().max() / want[k].double().abs().max().clamp_min(1e-30)).item() for k in GRAD_SAMPLE}
 
 
+def grad_cosines(want):
+    """cosine between the GPU gradient and the oracle's, per sampled tensor: 1 - O(noise^2) for a correct tensor, ~0 for a permuted one."""
+    out = {}
+    for k in GRAD_SAMPLE:
+        a, b = gpu_step.gsel[k].double().flatten(), want[k].double().flatten()
+        out[k] = (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+    return out
+
+
 def check_match(got, want):
     locs, cats, xywh, anc = got
     rlocs, rcats, rxywh, ranc = want
@@ -135,10 +144,14 @@ def test_config3_bf16_full_size_step_vs_oracle(oracle_step):
     assert max(herr) < 1.3e-1                                                   # bf16 activations through 75 layers, random init
     assert np.median(rel) < 1e-2 and rel.max() < 1.2e-1
     # element by element (round 4): bf16 storage of every activation and activation gradient leaves each dW element a few percent of
-    # the tensor's scale from the fp32 oracle; a mis-packed tap or channel would read ~1.  Gate = 2 x the worst value observed.
+    # the tensor's scale from the fp32 oracle (observed: up to 0.25 at the worst ELEMENT of a tensor whose norm is off by < 4e-2); a
+    # mis-packed tap or channel would read ~1 -- and the fp32 run below, same kernels' fp32 siblings and the same host code, is at 6e-5.
     ew = elementwise_grad_errors(oracle_step['gsel'])
     print('config3 bf16 element-wise gradient error / tensor scale: ' + ', '.join(f'{k} {v:.2e}' for k, v in ew.items()))
     assert max(ew.values()) < BF16_ELEMENTWISE_GATE, max(ew, key=ew.get)
+    cs = grad_cosines(oracle_step['gsel'])
+    print('config3 bf16 gradient cosine with the oracle: min %.5f (%s)' % (min(cs.values()), min(cs, key=cs.get)))
+    assert min(cs.values()) > 0.98, min(cs, key=cs.get)
 
 
 def test_config3_fp32_full_size_step_vs_oracle(oracle_step):
@@ -155,3 +168,5 @@ def test_config3_fp32_full_size_step_vs_oracle(oracle_step):
     ew = elementwise_grad_errors(oracle_step['gsel'])
     print('config3 fp32 element-wise gradient error / tensor scale: ' + ', '.join(f'{k} {v:.2e}' for k, v in ew.items()))
     assert max(ew.values()) < 5e-3, max(ew, key=ew.get)                         # exact-fp32 MFMA path: north_star's 1e-3 on loss / grads, 5e-3 at the worst ELEMENT
+    cs = grad_cosines(oracle_step['gsel'])
+    assert min(cs.values()) > 1 - 1e-6, min(cs, key=cs.get)
