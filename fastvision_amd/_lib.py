@@ -84,6 +84,7 @@ PROTOTYPES = {
     'fva_conv_pack_weights_tiled': (_I, [_P, _I, _I, _P]),
     'fva_conv_last_kernel': (C.c_char_p, []),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv1x1_fwd_apply': (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),

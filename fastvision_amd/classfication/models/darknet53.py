@@ -119,7 +119,10 @@ class Darknet(nn.Module):
         x = self.conv0(x)
         taps = []
         for stage in range(1, 6):
-            x = getattr(self, f'res{stage}')(getattr(self, f'conv{stage}')(x))
+            # inside a stage every block's output is consumed by the next block's conv1 (1x1) first: its apply pass may ride in that
+            # launch (ops.defer_apply_scope); the stage's last output is materialised when the scope closes
+            with ops.defer_apply_scope():
+                x = getattr(self, f'res{stage}')(getattr(self, f'conv{stage}')(x))
             taps.append(x)
         if self.including_top:      # classifier top: outside the accelerated path, plain torch ops on the fp32 copy
             out = torch.flatten(self.gap(taps[4].float()), 1)

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
             Vec16<T> out;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                float o = silu_f(v[u].get(e) * sc[e] + sh[e]);
+                float o = bn_silu_fwd_elem(v[u].get(e), sc[e], sh[e]);
                 if (has_res) o += r[u].get(e);
                 out.set(e, ok[u] ? o : 0.f);
             }

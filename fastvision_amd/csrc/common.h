@@ -83,6 +83,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // competes with the memory pipeline in the HBM-bound BatchNorm / SiLU kernels and in fused conv epilogues
 __device__ __forceinline__ float sigm_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
 __device__ __forceinline__ float silu_f(float u) { return u * sigm_fast(u); }
+// forward apply, per element: z = SiLU(y * scale + shift) (bn_act.hip's apply pass and the fused A-operand path of conv_igemm.hip share it,
+// so that z has the same bits wherever it is produced)
+__device__ __forceinline__ float bn_silu_fwd_elem(float y, float sc, float sh) { return silu_f(__builtin_fmaf(y, sc, sh)); }
 __device__ __forceinline__ float silu_grad(float u) {
     const float s = sigm_fast(u);
     return s * (1.f + u * (1.f - s));

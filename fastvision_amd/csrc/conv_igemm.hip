@@ -51,6 +51,14 @@ struct IgemmParams {
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_rstd;
     float* bnb_part;
     int bnb_row0, bnb_C;
+    // AX (fva_conv1x1_fwd_apply): the A operand of a 1x1 convolution is PRODUCED by the kernel from the raw output of the block before
+    // it -- z = SiLU(ax_y * scale[c] + shift[c]) (+ ax_res), rounded to bf16 -- written once to the halo buffer ax_z (zero border
+    // included) for everybody else who reads z, and straight into the LDS operand tile for this convolution.
+    const void* ax_y;      // dense [M][C]
+    const void* ax_res;    // halo buffer [B][H + 2 ax_res_pad][W + 2 ax_res_pad][C], or NULL
+    void* ax_z;            // halo buffer [B][H + 2 ax_pad][W + 2 ax_pad][C]
+    const float *ax_scale, *ax_shift;
+    int ax_pad, ax_res_pad, ax_H, ax_W;
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
     int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
@@ -142,6 +150,7 @@ __device__ __forceinline__ float bnact_f(const IgemmParams& p, float v, int n) {
 #define FVA_NT_STORES 1
 #endif
 __device__ __forceinline__ bf16x8 ld_stream(const bf16_t* p) { return *(const bf16x8*)p; }
+__device__ __forceinline__ void st_stream_keep(bf16_t* p, bf16x8 v) { *(bf16x8*)p = v; }   // an output the NEXT launches read: keep it in cache
 __device__ __forceinline__ void st_stream(bf16_t* p, bf16x8 v) {
 #if FVA_NT_STORES
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);
@@ -271,8 +280,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int EPI, int NSTAGE>
+template <typename T, int BM, int BN, int EPI, int NSTAGE, bool AX = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const IgemmParams p) {
+    static_assert(!AX || (sizeof(T) == 2 && EPI == EPI_STATS), "the produced-operand form is the bf16 training forward of a 1x1 layer");
     constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;               // 128-byte rows
     constexpr int WN = BN / 64;               // waves along n
@@ -445,16 +455,163 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         for (int j = 0; j < COEF_PER_THREAD; ++j) coef_tab[tid + j * NT] = coef_v[j];
     }
     stamp(7);
-    load_tile(0, 0);
-    if (p.ktiles > 1) load_tile(1, 1);
     int st_cur = 0;
+    // ---- AX: this thread's rows of the A tile (the DMA mapping: row (i * NW + w) * 8 + lrow, source chunk `chunk` lands at LDS slot
+    // lane & 7), as 32-bit element offsets into y / z / the residual (the host keeps all three below 2^31 elements).  Two register sets
+    // of raw operands where they fit (the 128 x 128 tile): k-tile kt + 1 is in flight while k-tile kt is transformed -------------
+    constexpr int AXS = (AX && BM == 128) ? 2 : 1;
+    uint32_t ax_yo[AX ? A_ITERS : 1], ax_zo[AX ? A_ITERS : 1], ax_ro[AX ? A_ITERS : 1], ax_fl[AX ? A_ITERS : 1];
+    bf16x8 ax_ry[AXS][AX ? A_ITERS : 1], ax_rr[AXS][AX ? A_ITERS : 1];
+    (void)ax_yo; (void)ax_zo; (void)ax_ro; (void)ax_fl; (void)ax_ry; (void)ax_rr;
+    // the eight scales / shifts of a k-tile: from an LDS table [2][C] (the 128 x 128 tile: the k-offset table's LDS, unused in this
+    // form; the host keeps C <= 512) or fetched with the raw operands (the thin tile has no LDS to spare and a single register set)
+    constexpr bool AXT = AX && USE_KTAB;
+    float* ax_tab = (float*)ktab;
+    f32x4 ax_csc[2], ax_csh[2];
+    (void)ax_csc; (void)ax_csh;
+    const bool ax_has_res = AX && p.ax_res != nullptr;
+    auto ax_issue_b = [&](int kt, int stage) {      // the weight tile of k-tile kt (1x1: one tap, channel slice kt) by LDS-DMA
+        char* sB = smem + stage * STAGE + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + kt * BK), LDS_PTR(sB + (i * NW + w) * 1024), 16, 0, 0);
+    };
+    auto ax_load_raw = [&](int kt, auto set_tag) {  // raw y (+ residual) chunks and the eight channels' coefficients of k-tile kt
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            ax_ry[S][i] = *(const bf16x8*)((const bf16_t*)p.ax_y + ax_yo[i] + kt * BK);
+            if (ax_has_res) ax_rr[S][i] = *(const bf16x8*)((const bf16_t*)p.ax_res + ax_ro[i] + kt * BK);
+        }
+        if constexpr (!AXT) {
+            const int c0 = kt * BK + chunk * 8;
+            ax_csc[0] = *(const f32x4*)(p.ax_scale + c0); ax_csc[1] = *(const f32x4*)(p.ax_scale + c0 + 4);
+            ax_csh[0] = *(const f32x4*)(p.ax_shift + c0); ax_csh[1] = *(const f32x4*)(p.ax_shift + c0 + 4);
+        }
+    };
+    // one k-tile of the produced operand: transform set S into the stage that MFMA(kt - 2) read last, send z on its way, barrier
+    auto ax_step = [&](int kt, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        if constexpr (AXS == 2) {
+            // the next k-tile's raw operands are requested FIRST and stay in flight across this step; the counted wait below lets
+            // exactly them stand and retires everything older: this k-tile's weights (LDS-DMA) and raw operands, the previous z stores
+            if (kt + 1 < p.ktiles) {
+                ax_load_raw(kt + 1, std::integral_constant<int, S ^ 1>{});
+                if (ax_has_res) wait_vmcnt<2 * A_ITERS>();
+                else wait_vmcnt<A_ITERS>();
+            } else {
+                wait_vmcnt<0>();
+            }
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t sAw = (uint32_t)(size_t)LDS_PTR(smem + st_cur * STAGE);
+        // this k-tile's eight scales and shifts from the LDS table (inline asm: see the store below)
+        f32x4 ax_sc[2], ax_sh[2];
+        if constexpr (!AXT) {
+            ax_sc[0] = ax_csc[0]; ax_sc[1] = ax_csc[1]; ax_sh[0] = ax_csh[0]; ax_sh[1] = ax_csh[1];
+        } else {
+            const uint32_t ta = (uint32_t)(size_t)LDS_PTR(ax_tab) + (uint32_t)(kt * BK + chunk * 8) * 4u;
+            const uint32_t tb = ta + (uint32_t)p.C * 4u;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ax_sc[0]) : "v"(ta));
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(ax_sc[1]) : "v"(ta));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ax_sh[0]) : "v"(tb));
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(ax_sh[1]) : "v"(tb));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // z leaves once, for every other reader of this activation; a row on the edge of its image also zeroes the halo pixels next
+        // to it (every border pixel has exactly one such neighbour row; the corners are taken by the corner rows)
+        bf16_t* zb = (bf16_t*)p.ax_z;
+        const bf16x8 zero = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        const int zrow = (p.ax_W + 2 * p.ax_pad) * p.C;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = bn_silu_fwd_elem((float)ax_ry[S][i][e], ax_sc[e >> 2][e & 3], ax_sh[e >> 2][e & 3]);
+                if (ax_has_res) o += (float)ax_rr[S][i][e];
+                t[e] = (bf16_t)o;
+            }
+            // inline asm: a store hipcc can see draws `s_waitcnt vmcnt(0)` in front of it while an LDS-DMA is in flight, which would
+            // also drain the raw operands just requested
+            asm volatile("ds_write_b128 %0, %1" ::"v"(sAw + (uint32_t)((i * NW + w) * 1024 + lane * 16)), "v"(t) : "memory");
+            const uint32_t f = ax_fl[i];
+            if (f & 1u) {
+                bf16_t* q = zb + ax_zo[i] + kt * BK;
+                st_stream_keep(q, t);
+                if (f & 30u) {
+                    if (f & 2u) *(bf16x8*)(q - p.C) = zero;
+                    if (f & 4u) *(bf16x8*)(q + p.C) = zero;
+                    if (f & 8u) {
+                        *(bf16x8*)(q - zrow) = zero;
+                        if (f & 2u) *(bf16x8*)(q - zrow - p.C) = zero;
+                        if (f & 4u) *(bf16x8*)(q - zrow + p.C) = zero;
+                    }
+                    if (f & 16u) {
+                        *(bf16x8*)(q + zrow) = zero;
+                        if (f & 2u) *(bf16x8*)(q + zrow - p.C) = zero;
+                        if (f & 4u) *(bf16x8*)(q + zrow + p.C) = zero;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < p.ktiles) {
+            ax_issue_b(kt + 1, st_cur ^ 1);
+            if constexpr (AXS == 1) ax_load_raw(kt + 1, std::integral_constant<int, 0>{});
+        }
+    };
+    if constexpr (AX) {
+        const int zp = p.ax_pad, rp = p.ax_res_pad;
+        const uint32_t zW = (uint32_t)(p.ax_W + 2 * zp), zHW = (uint32_t)(p.ax_H + 2 * zp) * zW;
+        const uint32_t rW = (uint32_t)(p.ax_W + 2 * rp), rHW = (uint32_t)(p.ax_H + 2 * rp) * rW;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            int m = m0 + (i * NW + w) * 8 + lrow;
+            const bool live = m < p.M;
+            m = live ? m : p.M - 1;
+            const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
+            const uint32_t oy = fd_div(rem, p.div_ow);
+            const uint32_t ox = rem - oy * (uint32_t)p.OW;
+            ax_yo[i] = (uint32_t)m * (uint32_t)p.C + chunk * 8;
+            ax_zo[i] = (b * zHW + (oy + zp) * zW + ox + zp) * (uint32_t)p.C + chunk * 8;
+            ax_ro[i] = (b * rHW + (oy + rp) * rW + ox + rp) * (uint32_t)p.C + chunk * 8;
+            ax_fl[i] = (live ? 1u : 0u) | (zp > 0 && live ? ((ox == 0 ? 2u : 0u) | (ox == (uint32_t)p.ax_W - 1 ? 4u : 0u) | (oy == 0 ? 8u : 0u) |
+                                                           (oy == (uint32_t)p.ax_H - 1 ? 16u : 0u)) : 0u);
+        }
+        // the coefficient table, written before the first LDS-DMA is in flight (hipcc drains vmcnt in front of an LDS store it can
+        // see once one is); read behind the first barrier at the earliest... by the threads that wrote other entries: hence the sync
+        if constexpr (AXT) {
+            for (int c = tid; c < p.C; c += NT) {
+                ax_tab[c] = p.ax_scale[c];
+                ax_tab[p.C + c] = p.ax_shift[c];
+            }
+            __syncthreads();
+        }
+        ax_issue_b(0, 0);
+        ax_load_raw(0, std::integral_constant<int, 0>{});
+    } else {
+        load_tile(0, 0);
+        if (p.ktiles > 1) load_tile(1, 1);
+    }
     stamp(1);
     for (int kt = 0; kt < p.ktiles; ++kt) {
+        if constexpr (AX) {
+            if (AXS == 1 || (kt & 1) == 0) ax_step(kt, std::integral_constant<int, 0>{});
+            else ax_step(kt, std::integral_constant<int, AXS - 1>{});
+            if (kt == 0) stamp(2);
+        } else {
         if (kt == 0 && p.ktiles > 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt == 0) stamp(2);
         if (kt >= 1 && kt + 1 < p.ktiles) load_tile(kt + 1, st_cur ^ 1);
+        }
         const char* sA = smem + st_cur * STAGE;
         const char* sB = sA + A_BYTES;
         st_cur ^= 1;
@@ -707,7 +864,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     stamp(5);
 }
 
-template <typename T, int BM, int BN, int EPI, int NSTAGE>
+template <typename T, int BM, int BN, int EPI, int NSTAGE, bool AX = false>
 int launch_one(const IgemmParams& p, hipStream_t s) {
     const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
@@ -725,13 +882,13 @@ int launch_one(const IgemmParams& p, hipStream_t s) {
     const int smem = NSTAGE * (BM + BN) * 128 + ktab_bytes + coef_bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, EPI, NSTAGE, AX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   NSTAGE * (BM + BN) * 128 + (BN >= 128 ? KTAB_MAX : 0) + coef_bytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, EPI, NSTAGE, AX>), dim3(mblocks * q.nblocks), dim3((BM / 64) * (BN / 64) * 64), smem, s, q);
     FVA_LAUNCH_CHECK("igemm_kernel");
-    fva_note_kernel(BM == 128 ? "igemm128" : "igemm256x64");
+    fva_note_kernel(AX ? (BM == 128 ? "igemm128ax" : "igemm256x64ax") : (BM == 128 ? "igemm128" : "igemm256x64"));
     return FVA_OK;
 }
 
@@ -1968,6 +2125,30 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
     FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return launch_pconv<EPI_STATS>(p, d->B, d->H, d->W, false, (hipStream_t)stream);
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
+}
+
+/* The forward apply pass of the block BEFORE a 1x1 convolution, fused into that convolution (igemm_kernel<..., AX>): see the header. */
+int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
+                          int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_conv1x1_fwd_apply");
+    if (rc) return rc;
+    if (!y_prev || !scale || !shift || !z || !w_fwd || !y) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: null pointer");
+    if (d->dtype != FVA_BF16 || d->ksize != 1 || d->stride != 1) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: a bf16 1x1 stride-1 layer only");
+    if (d->Cin % 64 || d->Cin > 512 || d->Cout % 8 || d->Cout > 128)
+        return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: needs Cin %% 64 == 0, Cin <= 512 and Cout <= 128 (one column block: every element is transformed once); got %d -> %d", d->Cin, d->Cout);
+    if (d->in_pad > 1 || res_pad < 0 || res_pad > 1) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: borders of 0 or 1 pixel only");
+    if ((int64_t)d->B * (d->H + 2) * (d->W + 2) * d->Cin >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: activation larger than 2^31 elements");
+    p.in = z;                       // not read by the kernel's operand path; kept for the address checks of the common code
+    p.wt = w_fwd;
+    p.out = y;
+    p.stats = stats_partial;
+    p.ax_y = y_prev; p.ax_res = residual; p.ax_z = z;
+    p.ax_scale = scale; p.ax_shift = shift;
+    p.ax_pad = d->in_pad; p.ax_res_pad = res_pad; p.ax_H = d->H; p.ax_W = d->W;
+    FvaProfileSpan span(0 | (1 << 8), 2.0 * p.M * (double)d->Cout * d->Cin, (hipStream_t)stream);
+    return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI_STATS, 2, true>(p, (hipStream_t)stream)
+                          : launch_one<bf16_t, 256, 64, EPI_STATS, 2, true>(p, (hipStream_t)stream);
 }
 
 int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,

@@ -263,12 +263,65 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
     _lib.call('fva_conv_dgrad', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), _stream())
 
 
-def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True):
+# ---- the forward apply pass of a block, deferred into the 1x1 convolution that consumes it -------------------------------------------
+# z = SiLU(BN(y)) (+ identity) of a block is an HBM round trip of its own (read y [+ identity], write z), and the residual blocks' conv1
+# (1x1) then reads z straight back.  Inside ``defer_apply_scope()`` -- Darknet.forward opens one per stage, around its own modules only --
+# a block may leave its apply pass PENDING (its z buffer allocated, not yet written); when the very next launch is a 1x1 layer that
+# the fused kernel serves (fva_conv1x1_fwd_apply: bf16 training, Cin % 64 == 0, Cout <= 128), that launch produces z on the way
+# to its own MFMAs -- same arithmetic, same bits, z written once, never read back by conv1.  Anything else that comes next, and the end
+# of the scope, run the ordinary apply launch first: a pending buffer never leaves the scope.
+_DEFER = {'depth': 0, 'pending': None, 'on': os.environ.get('FVA_FUSE_APPLY', '1') != '0', 'fused': 0}
+
+
+class defer_apply_scope:
+    def __enter__(self):
+        if _DEFER['depth'] == 0:
+            _DEFER['pending'] = None          # a scope that died with an exception leaves nothing behind
+        _DEFER['depth'] += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _DEFER['depth'] -= 1
+        if _DEFER['depth'] == 0:
+            if et is None:
+                flush_pending_apply()
+            else:
+                _DEFER['pending'] = None
+        return False
+
+
+def set_apply_fusion(on):
+    """Switch the deferred / fused forward apply on or off (default on; env FVA_FUSE_APPLY=0).  Returns the previous setting."""
+    prev, _DEFER['on'] = _DEFER['on'], bool(on)
+    return prev
+
+
+def flush_pending_apply():
+    """Run the apply pass that a block left pending, as its own launch."""
+    pd, _DEFER['pending'] = _DEFER['pending'], None
+    if pd is not None:
+        _lib.call('fva_bn_silu_apply', _code(pd['dtype']), _p(pd['y']), _p(pd['scale']), _p(pd['shift']), C.c_void_p(pd['res_ptr'] or 0), pd['res_pad'],
+                  C.c_void_p(pd['z_ptr']), 1, pd['B'], pd['H'], pd['W'], pd['C'], _stream())
+
+
+def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True, may_defer=False):
     """SiLU(BN(conv(x))) [+ residual].  x: logical [B,Cin,H,W]; x_ptr/x_pad describe its halo buffer.
-    Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape."""
+    Returns (z_view, saved).  ``residual`` = (ptr, pad) of a halo buffer with the output's shape.
+    ``may_defer``: the caller allows this block's apply pass to stay pending for the next launch (see defer_apply_scope)."""
     B, Cin, H, W = x.shape
     Cout, _, k, _ = weight.shape
     lib = _lib.load()
+    # an apply pass left pending by the block before: taken over by this launch when this is the 1x1 layer that reads exactly that
+    # buffer and the fused kernel serves it; run on its own otherwise
+    pend = _DEFER['pending']
+    if pend is not None:
+        if (pend['z_ptr'] == x_ptr and k == 1 and stride == 1 and training and dtype == torch.bfloat16 and pend['dtype'] == dtype
+                and Cin % 64 == 0 and Cin <= 512 and Cout <= 128 and Cout % 8 == 0 and x_pad == 1
+                and (pend['B'], pend['C'], pend['H'], pend['W']) == (B, Cin, H, W)):
+            _DEFER['pending'] = None
+        else:
+            flush_pending_apply()
+            pend = None
     x_src = _note_consumer(x) if need_ctx else None
     d = ConvDesc(_code(dtype), B, H, W, Cin, Cout, k, stride, x_pad, 1)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -300,7 +353,13 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
         stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
-        _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+        if pend is not None:
+            _lib.call('fva_conv1x1_fwd_apply', C.byref(d), _p(pend['y']), _p(pend['scale']), _p(pend['shift']), C.c_void_p(pend['res_ptr'] or 0),
+                      pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+            _DEFER['fused'] += 1
+            pend = None
+        else:
+            _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
         _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
                   bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
     else:
@@ -308,7 +367,13 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
     zbuf, z = halo_alloc(B, Cout, OH, OW, dtype, dev, 1)
     rp, rpad = (C.c_void_p(residual[0]), residual[1]) if residual is not None else (C.c_void_p(0), 0)
-    _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
+    if may_defer and training and _DEFER['on'] and _DEFER['depth'] > 0 and dtype == torch.bfloat16:
+        # the references keep y / scale / shift / the identity alive until the pass has run (they are saved for backward anyway)
+        _DEFER['pending'] = {'z_ptr': zbuf.data_ptr(), 'zbuf': zbuf, 'y': y, 'scale': scale, 'shift': shift, 'dtype': dtype,
+                             'res_ptr': residual[0] if residual is not None else None, 'res_pad': rpad, 'keep': x,
+                             'B': B, 'H': OH, 'W': OW, 'C': Cout}
+    else:
+        _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
     s = None
     if need_ctx:
         s = _Saved()
@@ -520,7 +585,7 @@ class ConvBNSiLUFn(torch.autograd.Function):
         require_gpu(x, 'ConvBlock')
         keep, x_ptr, x_pad = to_halo(x, dtype, weight.shape[2] // 2)
         need = _GRAD_ON[0] and any(ctx.needs_input_grad)
-        z, s = conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, need_ctx=need)
+        z, s = conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, need_ctx=need, may_defer=True)
         if s is not None:
             s.keep = keep
         ctx.s = s
@@ -541,6 +606,7 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, weight, gamma, beta, bn, training, dtype):
         require_gpu(images, 'stem')
+        flush_pending_apply()
         img = images.detach()
         if img.dtype != torch.float32 or not img.is_contiguous():
             img = img.float().contiguous()
@@ -661,7 +727,7 @@ class ResidualFn(torch.autograd.Function):
         need = _GRAD_ON[0] and any(ctx.needs_input_grad)
         z1, s1 = conv_block_fwd(x, x_ptr, x_pad, w1, g1, b1, bn1, training, 1, dtype, need_ctx=need)
         z1_ptr, z1_pad = halo_info(z1, dtype)
-        z2, s2 = conv_block_fwd(z1, z1_ptr, z1_pad, w2, g2, b2, bn2, training, 1, dtype, residual=(x_ptr, x_pad), need_ctx=need)
+        z2, s2 = conv_block_fwd(z1, z1_ptr, z1_pad, w2, g2, b2, bn2, training, 1, dtype, residual=(x_ptr, x_pad), need_ctx=need, may_defer=True)
         if need:
             s1.keep = keep
         ctx.s1, ctx.s2, ctx.x_like = s1, s2, x
@@ -683,6 +749,7 @@ class UpsampleConcatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, up, skip, up_first, dtype):
         require_gpu(up, 'UpSampling')
+        flush_pending_apply()
         _note_consumer(up)            # their gradients come from upcat_bwd, not from a dgrad epilogue
         _note_consumer(skip)
         ku, up_ptr, up_pad = to_halo(up, dtype, 0)
@@ -718,6 +785,7 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dtype):
         require_gpu(x, 'head')
+        flush_pending_apply()
         ctx.x_src = _note_consumer(x) if ctx.needs_input_grad[0] else None
         keep, x_ptr, x_pad = to_halo(x, dtype, 0)
         B, Cin, H, W = x.shape

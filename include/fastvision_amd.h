@@ -123,6 +123,15 @@ int fva_conv_patch_kernel(int on);
  * partial sums for BatchNorm: stats_partial[blk][0][c] = sum_y, [blk][1][c] = sum_y^2 over the rows of
  * that block (blk < fva_conv_stat_blocks()); they are reduced by fva_bn_finalize(). */
 int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats_partial, void* stream);
+/* Training forward of a 1x1 layer whose input z has not been produced yet: z = SiLU(y_prev * scale + shift) (+ residual) -- the
+ * apply pass of the block before it (fva_bn_silu_apply: same arithmetic, same bits) -- is computed in this launch's operand path,
+ * written ONCE to the halo buffer z (border d->in_pad <= 1 included, for every other reader of z: the residual identity, the weight
+ * gradient, the next block) and fed to the MFMAs from LDS without being read back: the separate apply launch and one read of z go
+ * (classfication/models/darknet53.py:46-63: a residual block's conv1 always follows the previous block's SiLU + add).  y / statistics
+ * as fva_conv_fwd (same tiles, same rows, same bits).  bf16; Cin % 64 == 0, Cin <= 512; Cout <= 128 (one column block, so that every element
+ * is transformed once); y_prev dense [B*H*W][Cin]; residual (optional) a halo buffer of z's shape with border res_pad. */
+int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
+                          int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream);
 /* Inference form: eval-mode BatchNorm folded into a per-channel affine and SiLU applied in the convolution's epilogue,
  * z = SiLU(conv(x) * scale[c] + shift[c]) (+ residual), written straight into the halo buffer z [B][OH+2p][OW+2p][Cout]
  * (interior by the MFMA kernel, zero border by a small second launch).  residual (optional) has z's geometry.

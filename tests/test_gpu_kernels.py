@@ -656,3 +656,91 @@ def test_wgrad_plan_is_a_process_setting_not_a_stream_property():
     assert torch.equal(out[0, 'main'], out[0, 'side']) and torch.equal(out[1, 'main'], out[1, 'side'])
     assert not torch.equal(out[0, 'main'], out[1, 'main'])         # this shape splits 14 ways alone and 7 ways beside: another order ...
     assert rel_err(out[0, 'main'], out[1, 'main']) < 1e-5          # ... of the same sum
+
+
+# ---- the forward apply pass fused into the 1x1 convolution that consumes it (fva_conv1x1_fwd_apply, round 4) ---------------------------
+@pytest.mark.parametrize('case', [
+    # B, C (= Cin of the 1x1 layer), N (= its Cout), H, W, residual
+    (2, 64, 32, 20, 24, True),        # thin tile (256 x 64), one k-tile
+    (3, 128, 64, 17, 9, True),        # thin tile, two k-tiles, M = 459: a row tail
+    (2, 256, 128, 16, 16, True),      # 128 x 128 tile, four k-tiles
+    (1, 256, 128, 13, 11, False),     # no identity (the down-sampling convolution feeding a stage's first block)
+    (32, 256, 128, 80, 80, True),     # the benchmark's res3 shape
+])
+def test_conv1x1_fused_apply_is_bit_identical_with_the_two_launches(case):
+    """z (incl. its zero border), the 1x1 layer's output and its BatchNorm partial statistics from ONE fused launch must equal, bit for
+    bit, what fva_bn_silu_apply followed by fva_conv_fwd write."""
+    from fastvision_amd import _lib, ops
+    B, Cc, N, H, W, with_res = case
+    lib = _lib.load()
+    dt = torch.bfloat16
+    code = ops._code(dt)
+    g = torch.Generator().manual_seed(Cc + H)
+    M = B * H * W
+    y_prev = torch.randn(M, Cc, generator=g).to(dev()).to(dt)
+    sc = (torch.rand(Cc, generator=g) + 0.5).to(dev())
+    sh = (torch.rand(Cc, generator=g) - 0.5).to(dev())
+    res = torch.randn(B, H + 2, W + 2, Cc, generator=g).to(dev()).to(dt) if with_res else None
+    w = (torch.randn(N, Cc, 1, 1, generator=g) / Cc ** 0.5).to(dev())
+    d = _lib.ConvDesc(code, B, H, W, Cc, N, 1, 1, 1, 1)
+    wf, _ = ops.packed_weights(w, d, dt, cache=False)
+    nblk = lib.fva_conv_stat_blocks(C.byref(d))
+    rows = lib.fva_bn_partial_rows(nblk)
+    st = ops._stream()
+    rp = ops._p(res) if with_res else C.c_void_p(0)
+    # reference: two launches
+    z0 = torch.full((B, H + 2, W + 2, Cc), float('nan'), device=dev(), dtype=dt)
+    y0 = torch.empty(M, N, device=dev(), dtype=dt)
+    s0 = torch.zeros(rows, 2, N, device=dev())
+    _lib.call('fva_bn_silu_apply', code, ops._p(y_prev), ops._p(sc), ops._p(sh), rp, 1, ops._p(z0), 1, B, H, W, Cc, st)
+    _lib.call('fva_conv_fwd', C.byref(d), ops._p(z0), ops._p(wf), ops._p(y0), ops._p(s0), st)
+    k_plain = lib.fva_conv_last_kernel().decode()
+    # fused
+    z1 = torch.full_like(z0, float('nan'))
+    y1 = torch.empty_like(y0)
+    s1 = torch.zeros_like(s0)
+    _lib.call('fva_conv1x1_fwd_apply', C.byref(d), ops._p(y_prev), ops._p(sc), ops._p(sh), rp, 1, ops._p(z1), ops._p(wf), ops._p(y1), ops._p(s1), st)
+    k_fused = lib.fva_conv_last_kernel().decode()
+    torch.cuda.synchronize()
+    assert k_fused == k_plain + 'ax', (k_plain, k_fused)
+    assert not torch.isnan(z1.float()).any(), 'part of z (or of its border) was not written'
+    assert torch.equal(z1.view(torch.int16), z0.view(torch.int16))
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(s1[:nblk], s0[:nblk])
+
+
+def test_deferred_apply_leaves_the_training_step_bit_identical():
+    """A whole YOLOv3 train step (B = 2, 128 px, bf16) with the deferred / fused forward apply on and off: identical loss, head outputs
+    and gradients, and the fused launch really ran (11 of Darknet-53's 23 residual conv1 layers have Cout <= 128)."""
+    import fastvision_amd
+    from fastvision_amd import ops
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.loss import Yolov3Loss
+    from fastvision_amd.synthetic import coco_anchors_px, synthetic_batch
+    images, tg = synthetic_batch(2, 128)
+    out = {}
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        for on in (False, True):
+            prev = ops.set_apply_fusion(on)
+            try:
+                torch.manual_seed(5)
+                net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+                             training=True).to(dev()).train()
+                crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+                n0 = ops._DEFER['fused']
+                pred = net(images.to(dev()))
+                fused = ops._DEFER['fused'] - n0
+                loss = crit(pred, tg.to(dev()))
+                loss.backward()
+                torch.cuda.synchronize()
+                out[on] = (loss.detach().clone(), [p.detach().clone() for p in pred], [p.grad.clone() for p in net.parameters()],
+                           [b.clone() for b in net.buffers()], fused)
+            finally:
+                ops.set_apply_fusion(prev)
+    assert out[False][4] == 0 and out[True][4] == 11, (out[False][4], out[True][4])
+    assert torch.equal(out[False][0], out[True][0])
+    for a, b in zip(out[False][1] + out[False][2] + out[False][3], out[True][1] + out[True][2] + out[True][3]):
+        assert torch.equal(a, b)
