@@ -327,8 +327,13 @@ def main():
         if reducer is not None:
             reducer.finish()
         opt.step()
-        return loss
+        return loss.detach()       # NOT the attached loss: see below
     step = eager_step
+    # (Round 4, found by the stall watchdog: a caller that keeps the attached `loss` of step k alive while it issues step k + 1 -- `loss =
+    # step()` does -- used to keep step k's autograd nodes, and with them this package's saved activations, alive: 11 GB more live memory,
+    # which torch's caching allocator went to the driver for inside the first timed steps -- 105 hipMalloc calls, one of which now and
+    # then took 300 ms: the "second timed step" stall of rounds 2 and 3.  The nodes now release their buffers in backward, as torch's own
+    # saved tensors do, and the benchmark keeps a detached loss.)
 
     def fence():
         if world > 1:
@@ -515,6 +520,7 @@ def main():
         # unknown; `host_issue_ms` shows which step).  A watchdog armed per step writes every thread's Python stack to stderr when a step
         # has not returned after 150 ms (five times its normal duration), so the next natural occurrence names the blocking call.
         import faulthandler
+        ms0 = torch.cuda.memory_stats(dev)
         t0 = time.perf_counter()
         step_marks[0].record()
         host_marks = [t0]
@@ -525,6 +531,7 @@ def main():
             step_marks[i + 1].record()
             host_marks.append(time.perf_counter())
         host_s = time.perf_counter() - t0          # time the host needed to ISSUE the steps (no sync inside a step)
+        ms1 = torch.cuda.memory_stats(dev)
         fence()
         elapsed = time.perf_counter() - t0
     gc.callbacks.remove(gc_watch)
@@ -630,6 +637,13 @@ def main():
             'host_issue_ms': [round((host_marks[i + 1] - host_marks[i]) * 1e3, 2) for i in range(args.steps)],
             'settle_windows_ms_per_step': settle_log,
             'gc_passes_in_timed_region': [g for g in gc_log if g[1] >= 1.0] or len(gc_log),
+            # the one host stall on record that the watchdog has caught so far (round 4: 330 ms in `dx = torch.empty(...)` inside a
+            # backward node) was torch's caching allocator on its slow path: segments it had to get from the driver inside the timed steps
+            'allocator': {'device_mallocs_in_timed_region': int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
+                          'device_frees_in_timed_region': int(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)),
+                          'alloc_retries': int(ms1.get('num_alloc_retries', 0)),
+                          'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 2 ** 30, 2),
+                          'active_peak_gb': round(ms1.get('active_bytes.all.peak', 0) / 2 ** 30, 2)},
         }
         if args.shapes:
             for k, v in sorted(kt.by_shape().items(), key=lambda kv: -kv[1][1]):

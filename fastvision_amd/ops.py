@@ -217,6 +217,11 @@ class _Saved:
     pass
 
 
+def _released(what):
+    return RuntimeError(f'fastvision_amd: {what}: the buffers saved for backward have already been released (a second backward pass through the same '
+                        'graph; as with torch\'s own saved tensors, this package keeps them for ONE backward pass)')
+
+
 # ---- BatchNorm-backward statistics in the epilogue of the dgrad launch that produces dz --------------------------------------
 # The first pass of a block's BatchNorm backward (sum dU, sum dU * xhat over the batch, dU = dz * SiLU') needs dz complete.  When
 # the block's output z has ONE consumer and that consumer is one of our convolutions, the dgrad launch of the consumer writes
@@ -595,9 +600,12 @@ class ConvBNSiLUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         s = ctx.s
+        if s is None:
+            raise _released('ConvBlock')
         keep, dz_ptr = to_dense(dz, s.dtype)
         dx, dw, dg, db = conv_block_bwd(s, dz_ptr, ctx.needs_input_grad[0])
-        return (_grad_like(dx, ctx.x_like) if dx is not None else None), dw, dg, db, None, None, None, None
+        x_like, ctx.s, ctx.x_like = ctx.x_like, None, None       # like torch's saved tensors: released by the backward pass that used them
+        return (_grad_like(dx, x_like) if dx is not None else None), dw, dg, db, None, None, None, None
 
 
 class StemFn(torch.autograd.Function):
@@ -658,7 +666,11 @@ class StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        if ctx.saved is None:
+            raise _released('stem')
         img, y, scale, shift, mean, rstd, gamma, dtype, training, wshape = ctx.saved
+        img4, w_saved = ctx.img4, getattr(ctx, 'weight', None)
+        ctx.saved = ctx.img4 = ctx.weight = None                  # released by the backward pass that uses them
         if not training:
             raise RuntimeError('fastvision_amd: backward through an eval-mode BatchNorm block is not supported')
         if ctx.needs_input_grad[0]:
@@ -670,22 +682,22 @@ class StemFn(torch.autograd.Function):
         keep, dz_ptr = to_dense(dz, dtype)
         if y is None:
             # fused bf16 path: both BatchNorm-backward passes recompute conv0 from the packed image, dY lands in a halo buffer
-            w = ctx.weight
+            w = w_saved
             nb = lib.fva_stem_fused_blocks(B, H, W)
             part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
-            _lib.call('fva_stem_fused', 2, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), None, None,
+            _lib.call('fva_stem_fused', 2, _p(img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), None, None,
                       _p(part), B, Cin, H, W, _stream())
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
             dbeta = torch.empty_like(dgamma)
             coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
             _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
             dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
-            _lib.call('fva_stem_fused', 3, _p(ctx.img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
+            _lib.call('fva_stem_fused', 3, _p(img4), _p(w), C.c_void_p(dz_ptr), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
                       _p(dy), None, B, Cin, H, W, _stream())
             raw = torch.empty((Cout, 4, 4, 3), dtype=torch.float32, device=dev)        # [co][kw][ci][kh]
             wsb = lib.fva_stem_wgrad_mfma_workspace()
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            _lib.call('fva_stem_wgrad_mfma', _p(ctx.img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
+            _lib.call('fva_stem_wgrad_mfma', _p(img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
             return None, raw[:, :3, :Cin, :].permute(0, 2, 3, 1).contiguous(), dgamma, dbeta, None, None, None
         nb = lib.fva_bn_bwd_blocks(code, M, Cout)
         part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
@@ -695,7 +707,7 @@ class StemFn(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], M, Cout, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
-        if ctx.img4 is not None and os.environ.get('FVA_STEM_WGRAD_MFMA', '1') != '0':
+        if img4 is not None and os.environ.get('FVA_STEM_WGRAD_MFMA', '1') != '0':
             # MFMA path: dY as a halo buffer, conv0 seen as 3 vertical taps over 4-pixel windows of the NHWC4 image
             dy = torch.empty((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
             _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(coef),
@@ -703,7 +715,7 @@ class StemFn(torch.autograd.Function):
             raw = torch.empty((Cout, 4, 4, 3), dtype=torch.float32, device=dev)        # [co][kw][ci][kh]
             wsb = lib.fva_stem_wgrad_mfma_workspace()
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            _lib.call('fva_stem_wgrad_mfma', _p(ctx.img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
+            _lib.call('fva_stem_wgrad_mfma', _p(img4), _p(dy), _p(raw), _p(ws), wsb, B, H, W, _stream())
             dw = raw[:, :3, :Cin, :].permute(0, 2, 3, 1).contiguous()
             return None, dw, dgamma, dbeta, None, None, None
         dy = torch.empty((M, Cout), dtype=dtype, device=dev)
@@ -736,10 +748,13 @@ class ResidualFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         s1, s2 = ctx.s1, ctx.s2
+        if s1 is None:
+            raise _released('ResidualBlock')
         keep, dout_ptr = to_dense(dout, s1.dtype)
         dz1, dw2, dg2, db2 = conv_block_bwd(s2, dout_ptr, True)
         dx, dw1, dg1, db1 = conv_block_bwd(s1, dz1.data_ptr(), ctx.needs_input_grad[0], addend_ptr=dout_ptr)
         gx = _grad_like(dx, ctx.x_like) if dx is not None else None
+        ctx.s1 = ctx.s2 = ctx.x_like = None                       # released by the backward pass that used them
         return gx, dw1, dg1, db1, None, dw2, dg2, db2, None, None, None
 
 
@@ -799,7 +814,10 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise _released('head')
         keep, x_ptr, x_pad, weight, dtype, x_like = ctx.saved
+        ctx.saved = None                                          # released by the backward pass that uses them
         lib = _lib.load()
         B, Cin, H, W = x_like.shape
         N = weight.shape[0]
@@ -824,6 +842,7 @@ class HeadFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((B, H, W, Cin), dtype=dtype, device=dev)
             _dgrad(d, dy, wd, dxb, None, ctx.x_src, dtype)
+            ctx.x_src = None
             dx = _grad_like(dxb, x_like)
         return dx, dwp[:N].contiguous(), dbias, None
 

@@ -90,6 +90,7 @@ class Fit:
                 loss.backward()
                 self.optimizer.step()
             losses.append(loss.detach())          # device tensor: no per-step host sync (the reference's tqdm .item() does one)
+            del pred, loss                        # the graph of this step must not outlive it (it would sit in memory beside the next step's)
             if epoch == self.start_epoch and batch_idx == 0:
                 _freeze_garbage_collector()
             if self.log_every and (batch_idx + 1) % self.log_every == 0:

@@ -744,3 +744,23 @@ def test_deferred_apply_leaves_the_training_step_bit_identical():
     assert torch.equal(out[False][0], out[True][0])
     for a, b in zip(out[False][1] + out[False][2] + out[False][3], out[True][1] + out[True][2] + out[True][3]):
         assert torch.equal(a, b)
+
+
+def test_saved_buffers_are_released_by_backward():
+    """Round 4 (found by the stall watchdog): the autograd nodes used to keep their saved activations for as long as anything referenced
+    the graph -- a caller holding the attached loss of step k while issuing step k + 1 kept two steps' activations alive.  They are
+    released by the backward pass that used them, like torch's own saved tensors; a second pass through the same graph raises."""
+    import fastvision_amd
+    from fastvision_amd.classfication.models.darknet53 import ResidualBlock
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        blk = ResidualBlock(64, 32).to(dev()).train()
+        x = torch.randn(2, 64, 16, 16, device=dev(), requires_grad=True)
+        y = blk(x)
+        gy = torch.randn_like(y.float())
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        torch.autograd.grad(y, x, gy.to(y.dtype), retain_graph=True)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() < before, 'the node still holds its saved buffers after backward'
+        with pytest.raises(RuntimeError, match='already been released'):
+            torch.autograd.grad(y, x, gy.to(y.dtype))
