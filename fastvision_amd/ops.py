@@ -573,6 +573,10 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     if need_dx:
         dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=dtype, device=dev)
         _dgrad(d, dy, s.wd, dx, addend_ptr, s.x_src, dtype)
+    # this block's saved state is spent: drop what it references (its output tensor may outlive the step in the caller's hands and
+    # still points here through _fva_prod; the side stream's launches keep their own references until the join)
+    s.__dict__.clear()
+    s.training, s.consumers, s.fused = False, 0, None
     return dx, dw, dgamma, dbeta
 
 
