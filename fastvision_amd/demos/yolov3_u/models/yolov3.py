@@ -34,13 +34,16 @@ class NeckV3(nn.Module):
         self.neck_out_large = ConvBlock3x3(in_channels=l // 2, out_channels=l)
 
     def forward(self, x_small, x_medium, x_large):
-        neck_small = self.neck_small(x_small)
+        with ops.defer_apply_scope():        # chains of this package's blocks: a 3x3 block's apply pass may ride in the next 1x1 launch
+            neck_small = self.neck_small(x_small)
         neck_out_small = self.neck_out_small(neck_small)
         cat_m = ops.upsample2_concat(self.up_sampling_small[0](neck_small), x_medium, up_first=False)
-        neck_medium = self.neck_medium(cat_m)
+        with ops.defer_apply_scope():
+            neck_medium = self.neck_medium(cat_m)
         neck_out_medium = self.neck_out_medium(neck_medium)
         cat_l = ops.upsample2_concat(self.up_sampling_medium[0](neck_medium), x_large, up_first=False)
-        neck_large = self.neck_large(cat_l)
+        with ops.defer_apply_scope():
+            neck_large = self.neck_large(cat_l)
         return neck_out_small, neck_out_medium, self.neck_out_large(neck_large)
 
 

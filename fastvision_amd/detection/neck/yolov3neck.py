@@ -22,7 +22,9 @@ class YoloBlock(nn.Module):
         self.conv5 = ConvBlock1x1(in_channels=out_channels * 2, out_channels=out_channels)
 
     def forward(self, x):
-        return self.conv5(self.conv4(self.conv3(self.conv2(self.conv1(x)))))
+        # a chain of this package's blocks only: a 3x3 block's apply pass may ride in the 1x1 launch that follows (ops.defer_apply_scope)
+        with ops.defer_apply_scope():
+            return self.conv5(self.conv4(self.conv3(self.conv2(self.conv1(x)))))
 
 
 class UpSampling(nn.Module):
