@@ -85,7 +85,6 @@ PROTOTYPES = {
     'fva_conv_last_kernel': (C.c_char_p, []),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_conv1x1_fwd_apply': (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
-    'fva_conv1x1_fwd_apply_stat_blocks': (_I, [_D]),
     'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
@@ -157,7 +156,7 @@ PROTOTYPES = {
     'fva_roi_align_bwd': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     'fva_nms_select': (_I, [_P, _P, _I, _I, _I, C.POINTER(NmsParams), _P, _L, _P, _P, _P, _P]),
 }
-UNCHECKED = {'fva_conv_patch_kernel', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_last_kernel', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv1x1_fwd_apply_stat_blocks', 'fva_conv_wgrad_workspace', 'fva_conv_wgrad_plan',
+UNCHECKED = {'fva_conv_patch_kernel', 'fva_rows_relu_bwd_rows', 'fva_colour_workspace', 'fva_conv_dgrad_stat_rows', 'fva_bias_relu_bwd_rows', 'fva_colsum_scratch_rows', 'fva_last_error', 'fva_version', 'fva_profile_stop', 'fva_conv_last_kernel', 'fva_conv_packed_elems', 'fva_conv_stat_blocks', 'fva_conv_wgrad_workspace', 'fva_conv_wgrad_plan',
              'fva_stem_stat_blocks', 'fva_stem_fused_blocks', 'fva_stem_wgrad_workspace', 'fva_stem_fwd_workspace', 'fva_stem_wgrad_mfma_workspace', 'fva_bn_bwd_blocks', 'fva_bn_partial_rows', 'fva_yolov3_loss_workspace',
              'fva_demo_loss_workspace', 'fva_nms_candidates_workspace', 'fva_nms_select_workspace'}
 

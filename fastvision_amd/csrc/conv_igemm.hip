@@ -59,8 +59,6 @@ struct IgemmParams {
     void* ax_z;            // halo buffer [B][H + 2 ax_pad][W + 2 ax_pad][C]
     const float *ax_scale, *ax_shift;
     int ax_pad, ax_res_pad, ax_H, ax_W;
-    int ax_rows;           // live rows per tile (<= BM, a multiple of 8): the launch is cut into tiles of ax_rows rows so that its blocks
-                           // fill whole rounds of the chip -- this form is bound by what a CU takes in, so a tile's time follows its LIVE rows
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
     int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
@@ -308,8 +306,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int mblk = logical / p.nblocks, nblk = logical - mblk * p.nblocks;
-    const int TR = AX ? p.ax_rows : BM;               // rows of this launch's tiles (AX: possibly fewer than the tile holds)
-    const int m0 = mblk * TR, n0 = nblk * BN;
+    const int m0 = mblk * BM, n0 = nblk * BN;
 
     // ---- per-lane source rows for the LDS-DMA (fixed for the whole k loop) -----------------------------
     const T* a_ptr[A_ITERS];
@@ -483,8 +480,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         constexpr int S = decltype(set_tag)::value;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            // (a dead row -- beyond M or beyond the tile's live rows -- still loads: its lanes would otherwise diverge around the
-            // counted wait; it reads row m of the NEXT tile, which that tile's block reads anyway: no extra traffic past L2)
             ax_ry[S][i] = *(const bf16x8*)((const bf16_t*)p.ax_y + ax_yo[i] + kt * BK);
             if (ax_has_res) ax_rr[S][i] = *(const bf16x8*)((const bf16_t*)p.ax_res + ax_ro[i] + kt * BK);
         }
@@ -577,8 +572,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             int m = m0 + (i * NW + w) * 8 + lrow;
-            const bool live = m < p.M && (i * NW + w) * 8 + lrow < TR;
-            m = m < p.M ? m : p.M - 1;
+            const bool live = m < p.M;
+            m = live ? m : p.M - 1;
             const uint32_t b = fd_div((uint32_t)m, p.div_ohw);
             const uint32_t rem = (uint32_t)m - b * (uint32_t)p.OHW;
             const uint32_t oy = fd_div(rem, p.div_ow);
@@ -688,10 +683,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                 f32x4 s1[4], s2[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) s1[nt] = s2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool whole = m0 + BM <= p.M && TR == BM;
+                const bool whole = m0 + BM <= p.M;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const bool live = whole || (m0 + wrow0 + mt * 16 + r < p.M && wrow0 + mt * 16 + r < TR);
+                    const bool live = whole || m0 + wrow0 + mt * 16 + r < p.M;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const f32x4 v = live ? acc.a[mt][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -863,7 +858,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
         __syncthreads();
         stamp(4);
-        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M && row < TR ? out_pixel(m) : (int64_t)-1; },
+        store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
                                                 EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr, coef_tab);
     }
     stamp(5);
@@ -871,7 +866,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 
 template <typename T, int BM, int BN, int EPI, int NSTAGE, bool AX = false>
 int launch_one(const IgemmParams& p, hipStream_t s) {
-    const int mblocks = cdiv(p.M, AX ? p.ax_rows : BM);
+    const int mblocks = cdiv(p.M, BM);
     IgemmParams q = p;
     q.nblocks = cdiv(p.N, BN);
     static const bool stamp_tiles = [] { const char* e = getenv("FVA_STAMP_IGEMM"); return e && atoi(e) != 0; }();   // tools/tile_timing.py pw
@@ -2132,19 +2127,6 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
 }
 
-// Live rows per tile of the fused form: the smallest tile count that fills whole rounds of the chip's 512 block slots (two blocks per
-// CU) with tiles no higher than the kernel's.  The launch streams (y, identity in; z, y out) at what the CUs take in, so a round's
-// time follows its live rows: 204800 rows as 1600 tiles of 128 are four rounds of 128 rows, as 1970 tiles of 104 four rounds of 104.
-static int ax_tile_rows(const fva_conv_desc* d) {
-    const int64_t M = (int64_t)d->B * d->H * d->W;
-    const int bm = wide_tile(d->Cout) ? 128 : 256, slots = 512;
-    const int64_t rounds = cdiv(M, (int64_t)slots * bm);
-    int rows = (int)cdiv(cdiv(M, rounds * slots), 8) * 8;
-    return rows < 8 ? 8 : rows > bm ? bm : rows;
-}
-
-int32_t fva_conv1x1_fwd_apply_stat_blocks(const fva_conv_desc* d) { return d ? cdiv((int64_t)d->B * d->H * d->W, ax_tile_rows(d)) : 0; }
-
 /* The forward apply pass of the block BEFORE a 1x1 convolution, fused into that convolution (igemm_kernel<..., AX>): see the header. */
 int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
                           int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream) {
@@ -2164,7 +2146,6 @@ int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const floa
     p.ax_y = y_prev; p.ax_res = residual; p.ax_z = z;
     p.ax_scale = scale; p.ax_shift = shift;
     p.ax_pad = d->in_pad; p.ax_res_pad = res_pad; p.ax_H = d->H; p.ax_W = d->W;
-    p.ax_rows = ax_tile_rows(d);
     FvaProfileSpan span(0 | (1 << 8), 2.0 * p.M * (double)d->Cout * d->Cin, (hipStream_t)stream);
     return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI_STATS, 2, true>(p, (hipStream_t)stream)
                           : launch_one<bf16_t, 256, 64, EPI_STATS, 2, true>(p, (hipStream_t)stream);

@@ -354,7 +354,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         return z, None
     y = torch.empty((M, Cout), dtype=dtype, device=dev)
     if training:
-        nblk = lib.fva_conv_stat_blocks(C.byref(d)) if pend is None else lib.fva_conv1x1_fwd_apply_stat_blocks(C.byref(d))
+        nblk = lib.fva_conv_stat_blocks(C.byref(d))
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
         stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)

@@ -127,15 +127,11 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
  * apply pass of the block before it (fva_bn_silu_apply: same arithmetic, same bits) -- is computed in this launch's operand path,
  * written ONCE to the halo buffer z (border d->in_pad <= 1 included, for every other reader of z: the residual identity, the weight
  * gradient, the next block) and fed to the MFMAs from LDS without being read back: the separate apply launch and one read of z go
- * (classfication/models/darknet53.py:46-63: a residual block's conv1 always follows the previous block's SiLU + add).  y as fva_conv_fwd
- * (same bits); statistics: fva_conv1x1_fwd_apply_stat_blocks(d) rows.  bf16; Cin % 64 == 0, Cin <= 512; Cout <= 128 (one column block, so that every element
+ * (classfication/models/darknet53.py:46-63: a residual block's conv1 always follows the previous block's SiLU + add).  y / statistics
+ * as fva_conv_fwd (same tiles, same rows, same bits).  bf16; Cin % 64 == 0, Cin <= 512; Cout <= 128 (one column block, so that every element
  * is transformed once); y_prev dense [B*H*W][Cin]; residual (optional) a halo buffer of z's shape with border res_pad. */
 int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
                           int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream);
-/* Rows of ITS statistics table: the fused form cuts the launch into tiles of fewer live rows than fva_conv_fwd's, so that its blocks
- * fill whole rounds of the chip (it is bound by what the CUs take in, not by its MFMAs); y and z do not depend on the cut, the
- * partial sums are those of another partition of the rows (the finalised statistics agree to fp32 summation order). */
-int32_t fva_conv1x1_fwd_apply_stat_blocks(const fva_conv_desc* d);
 /* Inference form: eval-mode BatchNorm folded into a per-channel affine and SiLU applied in the convolution's epilogue,
  * z = SiLU(conv(x) * scale[c] + shift[c]) (+ residual), written straight into the halo buffer z [B][OH+2p][OW+2p][Cout]
  * (interior by the MFMA kernel, zero border by a small second launch).  residual (optional) has z's geometry.
