@@ -79,21 +79,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
             s1 += red[0][k][cx];
             s2 += red[1][k][cx];
         }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma[c], bt = beta[c];
-        save_mean[c] = (float)mean;
-        save_rstd[c] = rstd;
-        const float sc = g * rstd;
-        scale[c] = sc;
-        shift[c] = bt - (float)mean * sc;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
+        const BnN n = bn_n(count);
+        const BnFwdCoef k = bn_fwd_coef(s1, s2, n, gamma[c], beta[c], eps);
+        save_mean[c] = k.mean;
+        save_rstd[c] = k.rstd;
+        scale[c] = k.scale;
+        shift[c] = k.shift;
+        if (running_mean) bn_running_update(running_mean, running_var, c, k, n, momentum);
     }
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
@@ -165,39 +157,79 @@ __device__ __forceinline__ Vec16<T> ld_last(const T* p) {
 #ifndef FVA_BN_UNROLL
 #define FVA_BN_UNROLL 2      // measured 1 / 2 / 4 (tools/bench_bn.py, sum over the layer shapes): fwd 348 / 337 / 340 us, bwd 514 / 506 / 504 us
 #endif
-template <typename T>
+// FIN: the batch statistics arrive as fixed-point accumulators that the producing convolution's tiles added to (common.h); every block
+// finalises the channels it needs in its prologue (the arithmetic of bn_finalize_kernel, so all blocks agree to the bit), the first
+// interior block also writes mean / rstd / scale / shift for the backward pass and updates the running statistics, and the last block
+// to finish -- a ticket on `counter` -- puts accumulator and counter back to zero for the next step.  No finalize launch.
+struct BnFwdAcc {
+    long long* acc;          // [2 words][2 sums][C]: the sums the producers added
+    long long* zero;         // may be null: another accumulator of 4 C words that this launch returns to zero (the layer's other direction)
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long* nbt;
+    float momentum, eps;
+    BnN n;
+    float *save_mean, *save_rstd, *scale, *shift;
+};
+struct BnBwdAcc {
+    long long* acc;          // sums of dU and dU * xhat
+    long long* zero;
+    const float *gamma, *rstd, *mean, *shift;
+    float *dgamma, *dbeta;
+    int accumulate;
+    BnN n;
+};
+__device__ __forceinline__ void fx_zero(long long* acc, int C, int tid, int nthreads) {
+    if (acc != nullptr)
+        for (int i = tid; i < 4 * C; i += nthreads) acc[i] = 0;
+}
+
+// the accumulator finalised by a launch of its own: for consumers that cannot do it in their prologue (the thin fused 1x1 tile, foreign code)
+__global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnFwdAcc fin, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        double s1, s2;
+        fx_load2(fin.acc, C, c, s1, s2);
+        const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
+        fin.save_mean[c] = k.mean; fin.save_rstd[c] = k.rstd; fin.scale[c] = k.scale; fin.shift[c] = k.shift;
+        if (fin.running_mean) bn_running_update(fin.running_mean, fin.running_var, c, k, fin.n, fin.momentum);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fin.acc[(size_t)i * C + c] = 0;       // nobody else reads it: this launch is the only consumer
+            if (fin.zero) fin.zero[(size_t)i * C + c] = 0;
+        }
+    }
+    if (c == 0 && fin.nbt) *fin.nbt += 1;
+}
+
+// One padded row of z per block and step (grid = rows for the plain form; the accumulator form runs at most 2048 blocks that walk the rows,
+// so that its prologue is paid once per block).  FIN: scale / shift come from the layer's accumulator -- all C channels once per block,
+// C / 256 per thread, through LDS (dynamic: 2 C floats), while the first row's loads are already in flight; block 0 also writes them out
+// for the backward pass, updates the running statistics and returns the OTHER direction's accumulator to zero (its own one is still being
+// read by the other blocks: the layer's backward pass zeroes that).
+template <typename T, bool FIN>
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const T* __restrict__ res,
-                                                            int res_pad, T* __restrict__ z, const HaloIdx h) {
+                                                            int res_pad, T* __restrict__ z, const HaloIdx h, const BnFwdAcc fin, int nrows) {
     constexpr int EPC = Vec16<T>::N, U = FVA_BN_UNROLL;
-    const int b = blockIdx.x / h.Hp, yp = blockIdx.x - b * h.Hp;
-    const int yy = yp - h.pad;
-    const bool row_in = yy >= 0 && yy < h.H;
+    extern __shared__ float fx_tab[];          // FIN: [2][C]
     const int row_chunks = h.Wp * h.cpp;
-    T* zrow = z + (int64_t)blockIdx.x * row_chunks * EPC;
-    if (!row_in) {   // a border row: zeros (block-uniform branch)
-        Vec16<T> zero;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
-        for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = zero;
-        return;
-    }
-    const T* yrow = y + ((int64_t)b * h.H + yy) * h.W * h.C;
-    const int rW = h.W + 2 * res_pad;
-    const T* rrow = res ? res + (((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + res_pad) * h.C : nullptr;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);  // cpp is a power of two (BN channel counts)
     // cpp divides 256, so a lane keeps the same channel chunk for the whole row: its coefficients live in registers
     const int cc = threadIdx.x & cmask;
-    float sc[EPC], sh[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = scale[cc * EPC + e];
-        sh[e] = shift[cc * EPC + e];
-    }
+    const int rW = h.W + 2 * res_pad;
     const bool has_res = res != nullptr;
-    for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
-        Vec16<T> v[U], r[U];
-        bool ok[U];
+    Vec16<T> v[U], r[U];
+    bool ok[U];
+    const T *yrow = nullptr, *rrow = nullptr;
+    auto set_row = [&](int row) -> bool {       // false: a border row
+        const int b = row / h.Hp, yy = row - b * h.Hp - h.pad;
+        if (yy < 0 || yy >= h.H) return false;
+        yrow = y + ((int64_t)b * h.H + yy) * h.W * h.C;
+        rrow = has_res ? res + (((int64_t)b * (h.H + 2 * res_pad) + yy + res_pad) * rW + res_pad) * h.C : nullptr;
+        return true;
+    };
+    auto load = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * 256;
@@ -213,17 +245,67 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
 #endif
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 256;
-            Vec16<T> out;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float o = bn_silu_fwd_elem(v[u].get(e), sc[e], sh[e]);
-                if (has_res) o += r[u].get(e);
-                out.set(e, ok[u] ? o : 0.f);
+    };
+    int row = blockIdx.x;
+    bool row_in = row < nrows && set_row(row);
+    if (FIN && row_in && (int)threadIdx.x < row_chunks) load(threadIdx.x);
+    float sc[EPC], sh[EPC];
+    if constexpr (FIN) {
+        const bool writer = blockIdx.x == 0;
+        for (int c = threadIdx.x; c < h.C; c += 256) {
+            double s1, s2;
+            fx_load2(fin.acc, h.C, c, s1, s2);
+            const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
+            fx_tab[c] = k.scale;
+            fx_tab[h.C + c] = k.shift;
+            if (writer) {
+                fin.save_mean[c] = k.mean; fin.save_rstd[c] = k.rstd; fin.scale[c] = k.scale; fin.shift[c] = k.shift;
+                if (fin.running_mean) bn_running_update(fin.running_mean, fin.running_var, c, k, fin.n, fin.momentum);
             }
-            if (i < row_chunks) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = out;
+        }
+        if (writer) {
+            if (threadIdx.x == 0 && fin.nbt) *fin.nbt += 1;
+            fx_zero(fin.zero, h.C, threadIdx.x, 256);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = fx_tab[cc * EPC + e];
+            sh[e] = fx_tab[h.C + cc * EPC + e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale[cc * EPC + e];
+            sh[e] = shift[cc * EPC + e];
+        }
+    }
+    bool first = FIN;
+    for (; row < nrows; row += gridDim.x, row_in = row < nrows && set_row(row)) {
+        T* zrow = z + (int64_t)row * row_chunks * EPC;
+        if (!row_in) {   // a border row: zeros (block-uniform branch)
+            Vec16<T> zero;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) zero.set(e, 0.f);
+            for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = zero;
+            first = false;
+            continue;
+        }
+        for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
+            if (!first) load(i0);
+            first = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                Vec16<T> out;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float o = bn_silu_fwd_elem(v[u].get(e), sc[e], sh[e]);
+                    if (has_res) o += r[u].get(e);
+                    out.set(e, ok[u] ? o : 0.f);
+                }
+                if (i < row_chunks) *(Vec16<T>*)(zrow + (int64_t)i * EPC) = out;
+            }
         }
     }
 }
@@ -233,7 +315,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ part, int64_t M, int C, int rows_per_block) {
+                                                            float* __restrict__ part, long long* acc, int64_t M, int C, int rows_per_block) {
     constexpr int EPC = Vec16<T>::N;
     extern __shared__ float red[];  // [2][rpi][C]
     const int cpp = C / EPC, rpi = 256 / cpp;
@@ -269,7 +351,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const int which = i / C, c = i - which * C;
         float s = 0.f;
         for (int k = 0; k < rpi; ++k) s += red[(which * rpi + k) * C + c];
-        part[((int64_t)blockIdx.x * 2 + which) * C + c] = s;
+        if (acc != nullptr) fx_atomic_add(acc, C, which, c, s);
+        else part[((int64_t)blockIdx.x * 2 + which) * C + c] = s;
     }
 }
 
@@ -300,36 +383,66 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
             s1 += red[0][k][cx];
             s2 += red[1][k][cx];
         }
-        const float db = (float)s1, dg = (float)s2;
-        dbeta[c] = accumulate ? dbeta[c] + db : db;
-        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-        const float a = gamma[c] * rstd[c];
-        coef[c] = a;
-        coef[C + c] = (float)(-(double)a * s2 / count);
-        coef[2 * C + c] = (float)(-(double)a * s1 / count);
+        const BnBwdCoef k = bn_bwd_coef(s1, s2, bn_n(count), gamma[c], rstd[c]);
+        dbeta[c] = accumulate ? dbeta[c] + k.dbeta : k.dbeta;
+        dgamma[c] = accumulate ? dgamma[c] + k.dgamma : k.dgamma;
+        coef[c] = k.a;
+        coef[C + c] = k.cb;
+        coef[2 * C + c] = k.cc;
     }
 }
 
-template <typename T>
+// FIN: dgamma, dbeta and the three coefficients come from the layer's backward accumulator (the sums the dgrad epilogues / the reduce
+// pass added), all C channels once per block through LDS (dynamic: 5 C floats); block 0 writes dgamma / dbeta and returns the layer's
+// FORWARD accumulator to zero (fin.zero) -- nobody reads that one any more; its own is zeroed by the layer's next forward pass.
+template <typename T, bool FIN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h, int nrows) {
+                                                           const float* __restrict__ coef, T* __restrict__ dy, const HaloIdx h, int nrows,
+                                                           const BnBwdAcc fin) {
     constexpr int EPC = Vec16<T>::N, U = FVA_BN_UNROLL;
+    extern __shared__ float fx_tab[];          // FIN: [5][C]
     const int row_chunks = h.Wp * h.cpp;
     const int cmask = h.cpp - 1, cshift = 31 - __builtin_clz(h.cpp);
     // lane-constant channel chunk (cpp divides 256): dY = a*dU + k1*y + k2 with k1 = coefB*rstd, k2 = coefC - k1*mean
     const int cc = threadIdx.x & cmask;
     float sc[EPC], sh[EPC], ka[EPC], k1[EPC], k2[EPC];
+    if constexpr (FIN) {
+        const bool writer = blockIdx.x == 0;
+        for (int c = threadIdx.x; c < h.C; c += 256) {
+            double s1, s2;
+            fx_load2(fin.acc, h.C, c, s1, s2);
+            const BnBwdCoef q = bn_bwd_coef(s1, s2, fin.n, fin.gamma[c], rstd[c]);
+            const BnBwdK k = bn_bwd_pack_coef(q.a, shift[c], mean[c], rstd[c], q.cb, q.cc);
+            fx_tab[c] = scale[c];
+            fx_tab[h.C + c] = k.sh;
+            fx_tab[2 * h.C + c] = k.a;
+            fx_tab[3 * h.C + c] = k.k1;
+            fx_tab[4 * h.C + c] = k.k2;
+            if (writer) {
+                fin.dbeta[c] = fin.accumulate ? fin.dbeta[c] + q.dbeta : q.dbeta;
+                fin.dgamma[c] = fin.accumulate ? fin.dgamma[c] + q.dgamma : q.dgamma;
+            }
+        }
+        if (writer) fx_zero(fin.zero, h.C, threadIdx.x, 256);
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        const int c = cc * EPC + e;
-        const BnBwdK k = bn_bwd_pack_coef(coef[c], shift[c], mean[c], rstd[c], coef[h.C + c], coef[2 * h.C + c]);
-        sc[e] = scale[c];
-        sh[e] = k.sh;
-        ka[e] = k.a;
-        k1[e] = k.k1;
-        k2[e] = k.k2;
+        for (int e = 0; e < EPC; ++e) {
+            const int c = cc * EPC + e;
+            sc[e] = fx_tab[c]; sh[e] = fx_tab[h.C + c]; ka[e] = fx_tab[2 * h.C + c]; k1[e] = fx_tab[3 * h.C + c]; k2[e] = fx_tab[4 * h.C + c];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = cc * EPC + e;
+            const BnBwdK k = bn_bwd_pack_coef(coef[c], shift[c], mean[c], rstd[c], coef[h.C + c], coef[2 * h.C + c]);
+            sc[e] = scale[c];
+            sh[e] = k.sh;
+            ka[e] = k.a;
+            k1[e] = k.k1;
+            k2[e] = k.k2;
+        }
     }
     // one padded row per block
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
@@ -475,6 +588,8 @@ __global__ void cast_nhwc_kernel(const TS* __restrict__ src, int spad, TD* __res
     }
 }
 
+constexpr int ACC_GRID = 2048;    // blocks of the accumulator forms of the apply kernels (8 per CU): each walks rows, its prologue paid once
+
 inline int stream_grid(int64_t items) {
     int64_t g = (items + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -543,12 +658,56 @@ int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float*
     if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_silu_apply_kernel<bf16_t>, dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
-                           (const bf16_t*)residual, res_pad, (bf16_t*)z, h);
+        hipLaunchKernelGGL((bn_silu_apply_kernel<bf16_t, false>), dim3(B * h.Hp), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                           (const bf16_t*)residual, res_pad, (bf16_t*)z, h, BnFwdAcc(), B * h.Hp);
     else
-        hipLaunchKernelGGL(bn_silu_apply_kernel<float>, dim3(B * h.Hp), dim3(256), 0, s, (const float*)y, scale, shift,
-                           (const float*)residual, res_pad, (float*)z, h);
+        hipLaunchKernelGGL((bn_silu_apply_kernel<float, false>), dim3(B * h.Hp), dim3(256), 0, s, (const float*)y, scale, shift,
+                           (const float*)residual, res_pad, (float*)z, h, BnFwdAcc(), B * h.Hp);
     FVA_LAUNCH_CHECK("bn_silu_apply_kernel");
+    return FVA_OK;
+}
+
+static int fill_fwd_acc(const fva_bn_fwd_acc* a, int64_t M, BnFwdAcc& f, const char* who) {
+    if (!a || !a->acc || !a->gamma || !a->beta || !a->save_mean || !a->save_rstd || !a->scale || !a->shift)
+        return fva_fail(FVA_ERR_ARG, "%s: null pointer in the accumulator descriptor", who);
+    if (a->zero == a->acc) return fva_fail(FVA_ERR_ARG, "%s: `zero` must be another accumulator (this one is still being read)", who);
+    f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.gamma = a->gamma; f.beta = a->beta;
+    f.running_mean = a->running_mean; f.running_var = a->running_var; f.nbt = (long long*)a->num_batches_tracked;
+    f.momentum = a->momentum; f.eps = a->eps; f.n = bn_n((double)M);
+    f.save_mean = a->save_mean; f.save_rstd = a->save_rstd; f.scale = a->scale; f.shift = a->shift;
+    return FVA_OK;
+}
+
+int fva_bn_acc_finalize(const fva_bn_fwd_acc* acc, int64_t M, int C, void* stream) {
+    BnFwdAcc f = BnFwdAcc();
+    const int rc = fill_fwd_acc(acc, M, f, "fva_bn_acc_finalize");
+    if (rc) return rc;
+    if (C < 1 || M < 1) return fva_fail(FVA_ERR_ARG, "fva_bn_acc_finalize: bad size");
+    hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, f, C);
+    FVA_LAUNCH_CHECK("bn_acc_finalize_kernel");
+    return FVA_OK;
+}
+
+int fva_bn_silu_apply_acc(int dtype, const void* y, const fva_bn_fwd_acc* acc, const void* residual, int res_pad, void* z, int z_pad, int B,
+                          int H, int W, int C, void* stream) {
+    int rc = check_chan(dtype, C, "fva_bn_silu_apply_acc");
+    if (rc) return rc;
+    if (!y || !z) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply_acc: null pointer");
+    BnFwdAcc f = BnFwdAcc();
+    rc = fill_fwd_acc(acc, (int64_t)B * H * W, f, "fva_bn_silu_apply_acc");
+    if (rc) return rc;
+    const HaloIdx h = make_halo(B, H, W, C, z_pad, dtype == FVA_BF16 ? 8 : 4);
+    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply_acc: tensor too large");
+    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply_acc: C=%d must be a power of two (<= 256 chunks)", C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nrows = B * h.Hp, grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 2 * C * 4;
+    if (dtype == FVA_BF16)
+        hipLaunchKernelGGL((bn_silu_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, (const bf16_t*)y, nullptr, nullptr,
+                           (const bf16_t*)residual, res_pad, (bf16_t*)z, h, f, nrows);
+    else
+        hipLaunchKernelGGL((bn_silu_apply_kernel<float, true>), dim3(grid), dim3(256), smem, s, (const float*)y, nullptr, nullptr,
+                           (const float*)residual, res_pad, (float*)z, h, f, nrows);
+    FVA_LAUNCH_CHECK("bn_silu_apply_kernel<acc>");
     return FVA_OK;
 }
 
@@ -566,27 +725,41 @@ int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C) {
     return cdiv(M, bwd_rows_per_block(M, C, epc));
 }
 
-int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
-                           const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks, int64_t M, int C,
+static int bwd_reduce_impl(const char* who, int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_rstd, float* partial, int64_t* acc, int32_t nblocks, int64_t M, int C,
                            void* stream) {
-    int rc = check_chan(dtype, C, "fva_bn_silu_bwd_reduce");
+    int rc = check_chan(dtype, C, who);
     if (rc) return rc;
     const int epc = dtype == FVA_BF16 ? 8 : 4;
     const int cpp = C / epc;
-    if (cpp > 256 || 256 % cpp) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: C=%d unsupported", C);
-    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !partial) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: null pointer");
+    if (cpp > 256 || 256 % cpp) return fva_fail(FVA_ERR_ARG, "%s: C=%d unsupported", who, C);
+    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || (!partial && !acc)) return fva_fail(FVA_ERR_ARG, "%s: null pointer", who);
     const int rows = bwd_rows_per_block(M, C, epc);
-    if (nblocks != cdiv(M, rows)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: nblocks %d != %d", nblocks, cdiv(M, rows));
+    if (acc) nblocks = cdiv(M, rows);
+    if (nblocks != cdiv(M, rows)) return fva_fail(FVA_ERR_ARG, "%s: nblocks %d != %d", who, nblocks, cdiv(M, rows));
     const int smem = 2 * (256 / cpp) * C * 4;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblocks), dim3(256), smem, s, (const bf16_t*)dz, (const bf16_t*)y, scale,
-                           shift, save_mean, save_rstd, partial, M, C, rows);
+                           shift, save_mean, save_rstd, partial, (long long*)acc, M, C, rows);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblocks), dim3(256), smem, s, (const float*)dz, (const float*)y, scale,
-                           shift, save_mean, save_rstd, partial, M, C, rows);
+                           shift, save_mean, save_rstd, partial, (long long*)acc, M, C, rows);
     FVA_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     return FVA_OK;
+}
+
+int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks, int64_t M, int C,
+                           void* stream) {
+    if (!partial) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: null pointer");
+    return bwd_reduce_impl("fva_bn_silu_bwd_reduce", dtype, dz, y, scale, shift, save_mean, save_rstd, partial, nullptr, nblocks, M, C, stream);
+}
+
+int fva_bn_silu_bwd_reduce_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                               const float* save_mean, const float* save_rstd, int64_t* acc, int64_t M, int C, void* stream) {
+    if (!acc) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce_acc: null pointer");
+    return bwd_reduce_impl("fva_bn_silu_bwd_reduce_acc", dtype, dz, y, scale, shift, save_mean, save_rstd, nullptr, acc, 0, M, C, stream);
 }
 
 int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, int64_t M, int C, const float* gamma, const float* save_rstd,
@@ -614,24 +787,53 @@ int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, i
     return FVA_OK;
 }
 
-int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float* scale, const float* shift, const float* save_mean,
-                          const float* save_rstd, const float* coef, void* dy, int dy_pad, int B, int H, int W, int C, void* stream) {
-    int rc = check_chan(dtype, C, "fva_bn_silu_bwd_apply");
+static int bwd_apply_impl(const char* who, int dtype, const void* dz, const void* y, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_rstd, const float* coef, const fva_bn_bwd_acc* a, void* dy, int dy_pad, int B, int H, int W, int C,
+                          void* stream) {
+    int rc = check_chan(dtype, C, who);
     if (rc) return rc;
-    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || !coef || !dy) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: null pointer");
+    if (!dz || !y || !scale || !shift || !save_mean || !save_rstd || (!coef && !a) || !dy) return fva_fail(FVA_ERR_ARG, "%s: null pointer", who);
     const HaloIdx h = make_halo(B, H, W, C, dy_pad, dtype == FVA_BF16 ? 8 : 4);
-    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: tensor too large");
-    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: C=%d must be a power of two (<= 256 chunks)", C);
+    if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "%s: tensor too large", who);
+    if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "%s: C=%d must be a power of two (<= 256 chunks)", who, C);
     hipStream_t s = (hipStream_t)stream;
-    const int nrows = B * h.Hp, grid = nrows;
+    const int nrows = B * h.Hp;
+    if (a) {
+        if (!a->acc || !a->gamma || !a->dgamma || !a->dbeta) return fva_fail(FVA_ERR_ARG, "%s: null pointer in the accumulator descriptor", who);
+        if (a->zero == a->acc) return fva_fail(FVA_ERR_ARG, "%s: `zero` must be another accumulator (this one is still being read)", who);
+        BnBwdAcc f = BnBwdAcc();
+        f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.gamma = a->gamma; f.dgamma = a->dgamma; f.dbeta = a->dbeta;
+        f.accumulate = a->accumulate; f.n = bn_n((double)B * H * W);
+        const int grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 5 * C * 4;
+        if (dtype == FVA_BF16)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, (const bf16_t*)dz, (const bf16_t*)y,
+                               scale, shift, save_mean, save_rstd, nullptr, (bf16_t*)dy, h, nrows, f);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), smem, s, (const float*)dz, (const float*)y,
+                               scale, shift, save_mean, save_rstd, nullptr, (float*)dy, h, nrows, f);
+        FVA_LAUNCH_CHECK("bn_bwd_apply_kernel<acc>");
+        return FVA_OK;
+    }
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
-                           scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h, nrows);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(nrows), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
+                           scale, shift, save_mean, save_rstd, coef, (bf16_t*)dy, h, nrows, BnBwdAcc());
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dz, (const float*)y,
-                           scale, shift, save_mean, save_rstd, coef, (float*)dy, h, nrows);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(nrows), dim3(256), 0, s, (const float*)dz, (const float*)y,
+                           scale, shift, save_mean, save_rstd, coef, (float*)dy, h, nrows, BnBwdAcc());
     FVA_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return FVA_OK;
+}
+
+int fva_bn_silu_bwd_apply(int dtype, const void* dz, const void* y, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_rstd, const float* coef, void* dy, int dy_pad, int B, int H, int W, int C, void* stream) {
+    if (!coef) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply: null pointer");
+    return bwd_apply_impl("fva_bn_silu_bwd_apply", dtype, dz, y, scale, shift, save_mean, save_rstd, coef, nullptr, dy, dy_pad, B, H, W, C, stream);
+}
+
+int fva_bn_silu_bwd_apply_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift, const float* save_mean,
+                              const float* save_rstd, const fva_bn_bwd_acc* acc, void* dy, int dy_pad, int B, int H, int W, int C, void* stream) {
+    if (!acc) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_apply_acc: null pointer");
+    return bwd_apply_impl("fva_bn_silu_bwd_apply_acc", dtype, dz, y, scale, shift, save_mean, save_rstd, nullptr, acc, dy, dy_pad, B, H, W, C, stream);
 }
 
 int fva_upsample2_concat_fwd(int dtype, const void* up, int up_pad, const void* skip, int skip_pad, void* out, int B, int h, int w,

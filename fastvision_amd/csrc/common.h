@@ -91,6 +91,98 @@ __device__ __forceinline__ float silu_grad(float u) {
     return s * (1.f + u * (1.f - s));
 }
 
+// ---- BatchNorm statistics summed by integer atomics (round 4) ------------------------------------------------------------------------
+// A convolution epilogue leaves, per tile and channel, two fp32 partial sums.  Until round 4 they went to a table that a separate launch
+// folded (bn_finalize / bn_prereduce + bn_bwd_finalize: 197 latency-bound launches per YOLOv3 step on the critical chain, 2.1 ms of it).
+// Now every tile ADDS its partials into one accumulator per channel and the pass that consumes the statistics (the apply kernel, or the
+// fused 1x1 convolution) finalises them in its own prologue.  Adding in floating point would make the result depend on the order in which
+// the tiles arrive; the accumulator is therefore a two-word FIXED-POINT number -- hi in units of 2^-8, lo in units of 2^-56, both int64
+// -- into which a partial is split exactly: integer addition is associative, so the sum is the same bits whatever the order
+// (deterministic run to run), and it carries every bit of a partial down to 2^-56 (an fp32 partial of magnitude >= 2^-32 exactly).
+// A non-finite partial poisons the accumulator (hi += 2^62): the finalised value reads NaN, as a floating-point sum would.
+struct FxSplit {
+    long long hi, lo;
+};
+__device__ __forceinline__ FxSplit fx_split(float p) {
+    FxSplit r;
+    if (!(__builtin_fabsf(p) < 1.0e15f)) {          // NaN, Inf, or beyond any plausible sum
+        r.hi = 1ll << 62;
+        r.lo = 0;
+        return r;
+    }
+    const double d = (double)p;
+    r.hi = __double2ll_rn(d * 256.0);
+    const double rest = d - (double)r.hi * (1.0 / 256.0);         // exact: |rest| <= 2^-9 and no finer than ulp(p)
+    r.lo = __double2ll_rn(rest * 72057594037927936.0);            // 2^56
+    return r;
+}
+// Accumulator of one BatchNorm layer and direction: int64 acc[2 words (hi, lo)][2 sums][C] -- a wave that adds 32 channels of both sums
+// touches two contiguous 256-byte runs per word, the shape the memory-side atomic units take at full rate.  A layer has one for each
+// direction (forward: sums of y, y^2; backward: sums of dU, dU * xhat); the consumer of one direction returns the OTHER one to zero (its
+// own is still being read by its other blocks), so both are zero again when their producers next run -- graph replays included.
+__device__ __forceinline__ void fx_atomic_add(long long* acc, int C, int which, int c, float p) {
+    const FxSplit s = fx_split(p);
+    atomicAdd((unsigned long long*)acc + (size_t)which * C + c, (unsigned long long)s.hi);
+    atomicAdd((unsigned long long*)acc + (size_t)(2 + which) * C + c, (unsigned long long)s.lo);
+}
+__device__ __forceinline__ double fx_value(long long hi, long long lo) {
+    if (hi >= (1ll << 60) || hi <= -(1ll << 60)) return __builtin_nan("");
+    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 72057594037927936.0);
+}
+__device__ __forceinline__ void fx_load2(const long long* acc, int C, int c, double& s1, double& s2) {
+    s1 = fx_value(acc[c], acc[(size_t)2 * C + c]);
+    s2 = fx_value(acc[(size_t)C + c], acc[(size_t)3 * C + c]);
+}
+// forward: batch statistics -> the coefficients of the apply pass.  Written to be cheap per channel (consumer kernels run it in their
+// prologue, every block): the pixel count comes as its reciprocal, and 1 / sqrt is v_rsq_f32 plus one Newton step (error < 1 ulp of
+// fp32) instead of a double-precision division and square root (~100 instructions each on this chip).
+struct BnN {
+    double inv, unbias;      // 1 / count;  count / (count - 1): the factor of the unbiased variance for the running estimate
+};
+__host__ __device__ inline BnN bn_n(double count) {
+    BnN n;
+    n.inv = 1.0 / count;
+    n.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+    return n;
+}
+struct BnFwdCoef {
+    float mean, rstd, scale, shift;
+    double var;
+};
+__device__ __forceinline__ BnFwdCoef bn_fwd_coef(double s1, double s2, const BnN& n, float gamma, float beta, float eps) {
+    BnFwdCoef k;
+    const double mean = s1 * n.inv;
+    double var = __builtin_fma(s2, n.inv, -mean * mean);
+    if (var < 0.0) var = 0.0;
+    k.var = var;
+    const float x = (float)(var + (double)eps);
+    float r = __builtin_amdgcn_rsqf(x);
+    r = r * __builtin_fmaf(-0.5f * x * r, r, 1.5f);
+    k.rstd = r;
+    k.mean = (float)mean;
+    k.scale = gamma * k.rstd;
+    k.shift = __builtin_fmaf(-k.mean, k.scale, beta);
+    return k;
+}
+// unbiased variance for the running estimate (nn.BatchNorm2d, training mode)
+__device__ __forceinline__ void bn_running_update(float* running_mean, float* running_var, int c, const BnFwdCoef& k, const BnN& n, float momentum) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * k.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(k.var * n.unbias);
+}
+// backward: sums of dU and dU * xhat -> dgamma, dbeta and the three coefficients of the second pass (the arithmetic of bn_bwd_finalize_kernel)
+struct BnBwdCoef {
+    float dbeta, dgamma, a, cb, cc;
+};
+__device__ __forceinline__ BnBwdCoef bn_bwd_coef(double s1, double s2, const BnN& n, float gamma, float rstd) {
+    BnBwdCoef k;
+    k.dbeta = (float)s1;
+    k.dgamma = (float)s2;
+    k.a = gamma * rstd;
+    k.cb = (float)(-(double)k.a * s2 * n.inv);
+    k.cc = (float)(-(double)k.a * s1 * n.inv);
+    return k;
+}
+
 // ---- second pass of the BatchNorm + SiLU backward, per element (bn_act.hip's apply kernels and the apply "rider" of the weight-gradient
 // kernels share these, so that a pass produces the same bits wherever it runs):  dY = a * dU + k1 * y + k2,  dU = dz * SiLU'(y * a + shift),
 // a = gamma * rstd (= the forward scale), k1 = coefB * rstd, k2 = coefC - k1 * mean  (coef = fva_bn_bwd_finalize's [3][C] table).

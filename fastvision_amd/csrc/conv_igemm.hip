@@ -25,6 +25,7 @@ struct IgemmParams {
     const void* wt;
     void* out;
     float* stats;
+    long long* stats_acc;   // instead of the table `stats`: per-channel fixed-point accumulators acc[2][2][N] (common.h fx_atomic_add) that every tile ADDS to
     const float* bias;
     const float* scale;  // EPI_BNACT: per-output-channel affine (eval-mode BatchNorm folded in) before SiLU; NULL = 1 (bias only)
     int act;             // EPI_BNACT: 0 SiLU, 1 ReLU (VGG blocks of the two-stage head), 2 none
@@ -50,6 +51,7 @@ struct IgemmParams {
     const void* bnb_y;
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_rstd;
     float* bnb_part;
+    long long* bnb_acc;     // instead of bnb_part: the producer layer's backward accumulator (common.h fx_atomic_add)
     int bnb_row0, bnb_C;
     // AX (fva_conv1x1_fwd_apply): the A operand of a 1x1 convolution is PRODUCED by the kernel from the raw output of the block before
     // it -- z = SiLU(ax_y * scale[c] + shift[c]) (+ ax_res), rounded to bf16 -- written once to the halo buffer ax_z (zero border
@@ -59,6 +61,15 @@ struct IgemmParams {
     void* ax_z;            // halo buffer [B][H + 2 ax_pad][W + 2 ax_pad][C]
     const float *ax_scale, *ax_shift;
     int ax_pad, ax_res_pad, ax_H, ax_W;
+    // ... with the statistics of the block before in a fixed-point accumulator (common.h): finalised in this launch's prologue
+    long long* ax_acc;     // NULL: ax_scale / ax_shift are given
+    long long* ax_zero;
+    const float *ax_gamma, *ax_beta;
+    float *ax_rm, *ax_rv;
+    long long* ax_nbt;
+    float ax_momentum, ax_eps;
+    BnN ax_n;
+    float *ax_save_mean, *ax_save_rstd, *ax_scale_out, *ax_shift_out;
     long long* stamps;   // diagnostic (fva_conv_debug_stamps): [stamp_rows][8] wall-clock stamps of the block's phases (igemm_kernel)
     int stamp_rows;
     int pt_tx, pt_ty, pt_H, pt_W;   // pconv_kernel: tiles of 8 x 32 output pixels per image (x, y), output image size
@@ -132,7 +143,10 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
         for (int g = 0; g < G; ++g) t += red[(which * G + g) * BN + col];
         const int n = n0 + col;
         const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-        if (n < p.N) *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
+        if (n < p.N) {
+            if (p.bnb_acc != nullptr) fx_atomic_add(p.bnb_acc, p.bnb_C, which, n - sub * p.bnb_C, t);
+            else *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
+        }
     }
 }
 
@@ -469,6 +483,24 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
     float* ax_tab = (float*)ktab;
     f32x4 ax_csc[2], ax_csh[2];
     (void)ax_csc; (void)ax_csh;
+    // scale / shift of channel c: given, or finalised here from the accumulator the previous block's tiles added to (every thread that
+    // asks for a channel gets the same bits: same inputs, same arithmetic).  `store`: also written out for the backward pass.
+    auto ax_coef = [&](int c, bool store, float& sc_o, float& sh_o) {
+        if (!AXT || p.ax_acc == nullptr) {          // (the thin tile, which has neither LDS nor registers to spare, always gets them given)
+            sc_o = p.ax_scale[c];
+            sh_o = p.ax_shift[c];
+            return;
+        }
+        double s1, s2;
+        fx_load2(p.ax_acc, p.C, c, s1, s2);
+        const BnFwdCoef k = bn_fwd_coef(s1, s2, p.ax_n, p.ax_gamma[c], p.ax_beta[c], p.ax_eps);
+        sc_o = k.scale;
+        sh_o = k.shift;
+        if (store) {
+            p.ax_save_mean[c] = k.mean; p.ax_save_rstd[c] = k.rstd; p.ax_scale_out[c] = k.scale; p.ax_shift_out[c] = k.shift;
+            if (p.ax_rm) bn_running_update(p.ax_rm, p.ax_rv, c, k, p.ax_n, p.ax_momentum);
+        }
+    };
     const bool ax_has_res = AX && p.ax_res != nullptr;
     auto ax_issue_b = [&](int kt, int stage) {      // the weight tile of k-tile kt (1x1: one tap, channel slice kt) by LDS-DMA
         char* sB = smem + stage * STAGE + A_BYTES;
@@ -586,15 +618,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
         // the coefficient table, written before the first LDS-DMA is in flight (hipcc drains vmcnt in front of an LDS store it can
         // see once one is); read behind the first barrier at the earliest... by the threads that wrote other entries: hence the sync
+        ax_load_raw(0, std::integral_constant<int, 0>{});      // in flight across the table's (cold) accumulator reads
         if constexpr (AXT) {
-            for (int c = tid; c < p.C; c += NT) {
-                ax_tab[c] = p.ax_scale[c];
-                ax_tab[p.C + c] = p.ax_shift[c];
-            }
+            for (int c = tid; c < p.C; c += NT) ax_coef(c, logical == 0, ax_tab[c], ax_tab[p.C + c]);
             __syncthreads();
         }
+        if (AXT && p.ax_acc != nullptr && logical == 0) {     // the other direction's accumulator back to zero (this one is still being read)
+            if (tid == 0 && p.ax_nbt) *p.ax_nbt += 1;
+            if (p.ax_zero != nullptr)
+                for (int i = tid; i < 4 * p.C; i += NT) p.ax_zero[i] = 0;
+        }
         ax_issue_b(0, 0);
-        ax_load_raw(0, std::integral_constant<int, 0>{});
     } else {
         load_tile(0, 0);
         if (p.ktiles > 1) load_tile(1, 1);
@@ -672,7 +706,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 
     // ---- BatchNorm partial statistics: per-column sum and sum of squares over this block's valid rows ----
     if constexpr (EPI == EPI_STATS) {
-        if (p.stats != nullptr) {
+        if (p.stats != nullptr || p.stats_acc != nullptr) {
             // statistics of the fp32 accumulators (the bf16 rounding of the stored tile is zero-mean, 2^-9 relative:
             // far below the batch-statistics noise); full tiles take the mask-free path
             constexpr int WMc = BM / 64;
@@ -707,7 +741,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     float s = 0.f;
 #pragma unroll
                     for (int k = 0; k < WMc * 16; ++k) s += red[(which * WMc * 16 + k) * RP + col];
-                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    if (n0 + col < p.N) {
+                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    }
                 }
                 __syncthreads();
             } else {
@@ -742,7 +779,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     float s = 0.f;
 #pragma unroll
                     for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
-                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    if (n0 + col < p.N) {
+                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    }
                 }
                 __syncthreads();
             }
@@ -824,7 +864,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     for (int k = 0; k < WMc; ++k) t += red[(which * WMc + k) * BN + col];
                     const int n = n0 + col;
                     const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
-                    if (n < p.N) *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
+                    if (n < p.N) {
+                        if (p.bnb_acc != nullptr) fx_atomic_add(p.bnb_acc, p.bnb_C, which, n - sub * p.bnb_C, t);
+                        else *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
+                    }
                 }
             }
         }
@@ -860,6 +903,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         stamp(4);
         store_tile_bf16<EPI, BM, BN, NT, PITCH>(p, smem, tid, n0, mblk, [&](int row) { const int m = m0 + row; return m < p.M ? out_pixel(m) : (int64_t)-1; },
                                                 EPI == EPI_BNB ? y_pre : nullptr, PREFETCH ? a_pre : nullptr, coef_tab);
+    }
+    if constexpr (AX) {
+        // the blocks of this launch were the consumers of the previous block's accumulator: the last one to get here zeroes it
+
     }
     stamp(5);
 }
@@ -1061,7 +1108,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
     const bool full = (ty + 1) * TH <= p.pt_H && (tx + 1) * TW <= p.pt_W;
     auto row_ok = [&](int rr) { return ty * TH + (rr >> 5) < p.pt_H && tx * TW + (rr & 31) < p.pt_W; };
     if constexpr (EPI == EPI_STATS) {
-        if (p.stats != nullptr) {
+        if (p.stats != nullptr || p.stats_acc != nullptr) {
             f32x4 s1[NTILE], s2[NTILE];
 #pragma unroll
             for (int i = 0; i < NTILE; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1090,7 +1137,10 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 64; ++k) t += red[(which * 64 + k) * RP + col];
-                if (col < p.N) *(p.stats + ((int64_t)tile * 2 + which) * p.N + col) = t;
+                if (col < p.N) {
+                    if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, col, t);
+                    else *(p.stats + ((int64_t)tile * 2 + which) * p.N + col) = t;
+                }
             }
             __syncthreads();
         }
@@ -1622,7 +1672,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
         const int row_e = wr_e * WM + r_e, col_e = wc_e * 64 + 4 * g_e;
 
         if constexpr (EPI == EPI_STATS) {
-            if (p.stats != nullptr) {
+            if (p.stats != nullptr || p.stats_acc != nullptr) {
                 f32x4 s1[4], s2[4];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) s1[ni] = s2[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1653,7 +1703,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
                     float s = 0.f;
 #pragma unroll
                     for (int i = 0; i < 32; ++i) s += red[(which * 32 + i) * RP + col];
-                    if (n0 + col < p.N) *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    if (n0 + col < p.N) {
+                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
+                    }
                 }
                 __syncthreads();
             }
@@ -2128,12 +2181,23 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
 }
 
 /* The forward apply pass of the block BEFORE a 1x1 convolution, fused into that convolution (igemm_kernel<..., AX>): see the header. */
+static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const fva_bn_fwd_acc* prev,
+                                  const void* residual, int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial,
+                                  int64_t* acc_out, void* stream);
+
 int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
                           int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream) {
+    if (!scale || !shift) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: null pointer");
+    return conv1x1_fwd_apply_impl(d, y_prev, scale, shift, nullptr, residual, res_pad, z, w_fwd, y, stats_partial, nullptr, stream);
+}
+
+static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const fva_bn_fwd_acc* prev,
+                                  const void* residual, int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial,
+                                  int64_t* acc_out, void* stream) {
     IgemmParams p;
     int rc = setup_fwd(d, p, "fva_conv1x1_fwd_apply");
     if (rc) return rc;
-    if (!y_prev || !scale || !shift || !z || !w_fwd || !y) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: null pointer");
+    if (!y_prev || !z || !w_fwd || !y) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: null pointer");
     if (d->dtype != FVA_BF16 || d->ksize != 1 || d->stride != 1) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: a bf16 1x1 stride-1 layer only");
     if (d->Cin % 64 || d->Cin > 512 || d->Cout % 8 || d->Cout > 128)
         return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: needs Cin %% 64 == 0, Cin <= 512 and Cout <= 128 (one column block: every element is transformed once); got %d -> %d", d->Cin, d->Cout);
@@ -2143,12 +2207,52 @@ int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const floa
     p.wt = w_fwd;
     p.out = y;
     p.stats = stats_partial;
+    p.stats_acc = (long long*)acc_out;
     p.ax_y = y_prev; p.ax_res = residual; p.ax_z = z;
     p.ax_scale = scale; p.ax_shift = shift;
+    if (prev) {
+        p.ax_acc = (long long*)prev->acc; p.ax_zero = (long long*)prev->zero;
+        p.ax_gamma = prev->gamma; p.ax_beta = prev->beta; p.ax_rm = prev->running_mean; p.ax_rv = prev->running_var;
+        p.ax_nbt = (long long*)prev->num_batches_tracked; p.ax_momentum = prev->momentum; p.ax_eps = prev->eps;
+        p.ax_n = bn_n((double)p.M);
+        p.ax_save_mean = prev->save_mean; p.ax_save_rstd = prev->save_rstd; p.ax_scale_out = prev->scale; p.ax_shift_out = prev->shift;
+    }
     p.ax_pad = d->in_pad; p.ax_res_pad = res_pad; p.ax_H = d->H; p.ax_W = d->W;
     FvaProfileSpan span(0 | (1 << 8), 2.0 * p.M * (double)d->Cout * d->Cin, (hipStream_t)stream);
     return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI_STATS, 2, true>(p, (hipStream_t)stream)
                           : launch_one<bf16_t, 256, 64, EPI_STATS, 2, true>(p, (hipStream_t)stream);
+}
+
+int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, void* stream) {
+    IgemmParams p;
+    int rc = setup_fwd(d, p, "fva_conv_fwd_acc");
+    if (rc) return rc;
+    if (!x || !w_fwd || !y || !acc) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_acc: null pointer");
+    if (d->Cout % 8) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_acc: Cout %d not a multiple of 8", d->Cout);
+    p.in = x;
+    p.wt = w_fwd;
+    p.out = y;
+    p.stats_acc = (long long*)acc;
+    FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
+    if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return launch_pconv<EPI_STATS>(p, d->B, d->H, d->W, false, (hipStream_t)stream);
+    return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
+}
+
+int fva_conv1x1_fwd_apply_acc(const fva_conv_desc* d, const void* y_prev, const fva_bn_fwd_acc* prev, const void* residual, int32_t res_pad,
+                              void* z, const void* w_fwd, void* y, int64_t* acc_out, void* stream) {
+    if (!prev || !prev->scale || !prev->shift || !acc_out) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null pointer");
+    if (!prev->acc)          // the previous block's coefficients are given (finalised already: fva_bn_acc_finalize); only this layer's statistics accumulate
+        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
+    if (!prev->gamma || !prev->beta || !prev->save_mean || !prev->save_rstd || prev->zero == prev->acc)
+        return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null pointer in the accumulator descriptor");
+    if (!d) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null descriptor");
+    if (!wide_tile(d->Cout)) {   // the thin tile has no room for the prologue (264 registers with it): a small launch finalises, the fused one takes the arrays
+        const int OH = d->H, OW = d->W;
+        const int rc = fva_bn_acc_finalize(prev, (int64_t)d->B * OH * OW, d->Cin, stream);
+        if (rc) return rc;
+        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
+    }
+    return conv1x1_fwd_apply_impl(d, y_prev, nullptr, nullptr, prev, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
 }
 
 int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
@@ -2270,9 +2374,10 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
     p.addend = addend;
     p.out_pitch = d->Cin;
     if (f) {
-        if (!f->y || !f->scale || !f->shift || !f->mean || !f->rstd || !f->partial) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bnstats: null pointer");
+        if (!f->y || !f->scale || !f->shift || !f->mean || !f->rstd || (!f->partial && !f->acc)) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bnstats: null pointer");
         p.bnb_y = f->y; p.bnb_scale = f->scale; p.bnb_shift = f->shift; p.bnb_mean = f->mean; p.bnb_rstd = f->rstd;
         p.bnb_part = f->partial;
+        p.bnb_acc = (long long*)f->acc;
         p.bnb_row0 = 0;
         p.bnb_C = d->Cin;
     }

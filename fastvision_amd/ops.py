@@ -249,9 +249,9 @@ def _note_consumer(x):
     return src
 
 
-def _fuse_struct(src, part):
+def _fuse_struct(src, part, acc=None):
     return _lib.BnBwdFuse(src.y.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr(), src.mean.data_ptr(), src.rstd.data_ptr(),
-                          part.data_ptr())
+                          None if part is None else part.data_ptr(), None if acc is None else acc.data_ptr())
 
 
 def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
@@ -259,6 +259,14 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
     if (_BN_FUSE[0] and src is not None and src.consumers == 1 and src.training and src.dtype == dtype
             and src.M == d.B * d.H * d.W and src.d.Cout == d.Cin and not torch.is_grad_enabled()):
         rows = _lib.load().fva_conv_dgrad_stat_rows(C.byref(d))
+        if rows > 0 and getattr(src, 'acc', None) is not None:
+            # the producer layer keeps its statistics in accumulators: the epilogue ADDS the sums to its backward one
+            st = src.acc
+            st.produce(1)
+            fs = _fuse_struct(src, None, st.buf[1])
+            _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
+            src.fused = (None, 0, dx.data_ptr(), dx)
+            return
         if rows > 0:
             part = torch.empty((_lib.load().fva_bn_partial_rows(rows), 2, d.Cin), dtype=torch.float32, device=dx.device)
             fs = _fuse_struct(src, part)
@@ -305,8 +313,73 @@ def flush_pending_apply():
     """Run the apply pass that a block left pending, as its own launch."""
     pd, _DEFER['pending'] = _DEFER['pending'], None
     if pd is not None:
+        if pd['fin'] is not None:
+            _lib.call('fva_bn_silu_apply_acc', _code(pd['dtype']), _p(pd['y']), C.byref(pd['fin'].desc()), C.c_void_p(pd['res_ptr'] or 0), pd['res_pad'],
+                      C.c_void_p(pd['z_ptr']), 1, pd['B'], pd['H'], pd['W'], pd['C'], _stream())
+            pd['fin'].state.consumed(0)
+            return
         _lib.call('fva_bn_silu_apply', _code(pd['dtype']), _p(pd['y']), _p(pd['scale']), _p(pd['shift']), C.c_void_p(pd['res_ptr'] or 0), pd['res_pad'],
                   C.c_void_p(pd['z_ptr']), 1, pd['B'], pd['H'], pd['W'], pd['C'], _stream())
+
+
+# ---- BatchNorm statistics without a launch of their own ------------------------------------------------------------------------------
+# The table form (every tile of the convolution stores its partial sums, fva_bn_finalize folds them) costs one or two small launches
+# per layer, each a dependent step of the chain: 72 layers x (pre-reduce +) finalize = 2 ms of a 28 ms step (measured by leaving them out,
+# profiles/r04_experiments.md).  In the accumulator form every tile ADDS its partial sums to a per-layer fixed-point accumulator (two
+# int64 words per sum: integer addition is associative, so the result does not depend on the order of the atomics and stays
+# run-to-run bit-identical), and the launch that consumes the statistics -- the apply pass, or the fused 1x1 convolution that carries it --
+# turns them into scale / shift in its prologue, updates the running statistics from one block and returns the accumulator to zero.
+# The accumulator lives on the BatchNorm weight (one per layer, allocated once, zero between uses); `dirty` tracks a producer whose
+# consumer never ran (an exception in between): the next producer then clears it first.
+_BN_ACC = [os.environ.get('FVA_BN_ACC', '1') != '0']
+
+
+def set_bn_accumulators(on):
+    """Switch the accumulator form of the BatchNorm statistics on or off (default on; env FVA_BN_ACC=0).  Returns the previous setting."""
+    prev, _BN_ACC[0] = _BN_ACC[0], bool(on)
+    return prev
+
+
+class _AccState:
+    """The two accumulators of one BatchNorm layer (buf[0]: forward sums, buf[1]: backward sums) and what the host knows of them:
+    0 = zero, 1 = a producer has added to it, 2 = consumed (its sums are still there).  The normal sequence needs no clearing launch: each
+    direction's consumer zeroes the other direction's accumulator."""
+    __slots__ = ('buf', 'state')
+
+    def __init__(self, Cc, device):
+        self.buf = torch.zeros((2, 4 * Cc), dtype=torch.int64, device=device)
+        self.state = [0, 0]
+
+    def produce(self, which):
+        if self.state[which] != 0:          # left over from a pass whose other half never ran
+            self.buf[which].zero_()
+        self.state[which] = 1
+
+    def consumed(self, which):
+        self.state[which] = 2
+        self.state[1 - which] = 0           # the consumer returned the other direction's accumulator to zero
+
+
+def _acc_state(gamma):
+    Cc = gamma.numel()
+    st = getattr(gamma, '_fva_acc', None)
+    if st is None or st.buf.device != gamma.device or st.buf.shape[1] != 4 * Cc:
+        st = gamma._fva_acc = _AccState(Cc, gamma.device)
+    return st
+
+
+class _Fin:
+    """What the consumer of a layer's accumulator needs to finalise it (struct fva_bn_fwd_acc)."""
+
+    def __init__(self, state, gamma, beta, bn, mean, rstd, scale, shift):
+        self.state, self.keep = state, (gamma, beta, bn, mean, rstd, scale, shift)
+
+    def desc(self, given=False):
+        gamma, beta, bn, mean, rstd, scale, shift = self.keep
+        opt = lambda t: None if t is None else t.data_ptr()
+        return _lib.BnFwdAcc(None if given else self.state.buf[0].data_ptr(), self.state.buf[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                             opt(bn.rm), opt(bn.rv), opt(bn.nbt), bn.momentum, bn.eps,
+                             mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
 
 
 def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, dtype, residual=None, need_ctx=True, may_defer=False):
@@ -322,7 +395,8 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     if pend is not None:
         if (pend['z_ptr'] == x_ptr and k == 1 and stride == 1 and training and dtype == torch.bfloat16 and pend['dtype'] == dtype
                 and Cin % 64 == 0 and Cin <= 512 and Cout <= 128 and Cout % 8 == 0 and x_pad == 1
-                and (pend['B'], pend['C'], pend['H'], pend['W']) == (B, Cin, H, W)):
+                and (pend['B'], pend['C'], pend['H'], pend['W']) == (B, Cin, H, W)
+                and not (pend['fin'] is not None and pend['fin'].keep[0] is gamma)):      # one layer applied twice in a row: its accumulator would be read and written by one launch
             _DEFER['pending'] = None
         else:
             flush_pending_apply()
@@ -353,20 +427,42 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
                   C.c_void_p(residual[0] if residual is not None else 0), _p(zbuf), 1, _stream())
         return z, None
     y = torch.empty((M, Cout), dtype=dtype, device=dev)
+    fin = None
     if training:
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
-        stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
+        if _BN_ACC[0] and gamma.is_cuda:
+            st = _acc_state(gamma)
+            st.produce(0)
+            fin = _Fin(st, gamma, beta, bn, mean, rstd, scale, shift)
+            stats = None
+        else:
+            stats = torch.empty((lib.fva_bn_partial_rows(nblk), 2, Cout), dtype=torch.float32, device=dev)
         if pend is not None:
-            _lib.call('fva_conv1x1_fwd_apply', C.byref(d), _p(pend['y']), _p(pend['scale']), _p(pend['shift']), C.c_void_p(pend['res_ptr'] or 0),
-                      pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+            pf = pend['fin']
+            if fin is not None:
+                # the block before: its accumulator is finalised by this launch (pf), or its coefficients are final already
+                prev = pf.desc() if pf is not None else _lib.BnFwdAcc(None, None, None, None, None, None, None, 0.0, 0.0, None, None,
+                                                                      pend['scale'].data_ptr(), pend['shift'].data_ptr())
+                _lib.call('fva_conv1x1_fwd_apply_acc', C.byref(d), _p(pend['y']), C.byref(prev), C.c_void_p(pend['res_ptr'] or 0),
+                          pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), _stream())
+            else:
+                if pf is not None:
+                    _lib.call('fva_bn_acc_finalize', C.byref(pf.desc()), M, Cin, _stream())
+                _lib.call('fva_conv1x1_fwd_apply', C.byref(d), _p(pend['y']), _p(pend['scale']), _p(pend['shift']), C.c_void_p(pend['res_ptr'] or 0),
+                          pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
+            if pf is not None:
+                pf.state.consumed(0)
             _DEFER['fused'] += 1
             pend = None
+        elif fin is not None:
+            _lib.call('fva_conv_fwd_acc', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), _stream())
         else:
             _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
-        _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
-                  bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+        if fin is None:
+            _lib.call('fva_bn_finalize', _p(stats), nblk, stats.shape[0], M, Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), _p(bn.nbt),
+                      bn.momentum, bn.eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
     else:
         _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), C.c_void_p(0), _stream())
         _lib.call('fva_bn_eval_coeffs', Cout, _p(gamma), _p(beta), _p(bn.rm), _p(bn.rv), bn.eps, _p(scale), _p(shift), _stream())
@@ -376,7 +472,10 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         # the references keep y / scale / shift / the identity alive until the pass has run (they are saved for backward anyway)
         _DEFER['pending'] = {'z_ptr': zbuf.data_ptr(), 'zbuf': zbuf, 'y': y, 'scale': scale, 'shift': shift, 'dtype': dtype,
                              'res_ptr': residual[0] if residual is not None else None, 'res_pad': rpad, 'keep': x,
-                             'B': B, 'H': OH, 'W': OW, 'C': Cout}
+                             'B': B, 'H': OH, 'W': OW, 'C': Cout, 'fin': fin}
+    elif fin is not None:
+        _lib.call('fva_bn_silu_apply_acc', _code(dtype), _p(y), C.byref(fin.desc()), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
+        fin.state.consumed(0)
     else:
         _lib.call('fva_bn_silu_apply', _code(dtype), _p(y), _p(scale), _p(shift), rp, rpad, _p(zbuf), 1, B, OH, OW, Cout, _stream())
     s = None
@@ -387,6 +486,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         s.weight = weight
         s.training = training
         s.x_src, s.consumers, s.fused = x_src, 0, None
+        s.acc = fin.state if fin is not None else None
         if training:
             z._fva_prod = s
     return z, s
@@ -550,21 +650,34 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
     d, dtype, dev = s.d, s.dtype, s.y.device
     Cout, code = d.Cout, _code(s.dtype)
     fused, s.fused = s.fused, None
-    if fused is not None and fused[2] == dz_ptr:
-        part, nb = fused[0], fused[1]                   # the consumer's dgrad epilogue has already summed dU and dU * xhat
-    else:
-        nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
-        part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
-        _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-                  _p(part), nb, s.M, Cout, _stream())
-    del fused
+    have = fused is not None and fused[2] == dz_ptr     # the consumer's dgrad epilogue has already summed dU and dU * xhat of exactly this dz
     dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
     dbeta = torch.empty_like(dgamma)
-    coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-    _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
     dy = torch.empty((d.B, s.OH + 2, s.OW + 2, Cout), dtype=dtype, device=dev)
-    _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-              _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+    st = getattr(s, 'acc', None)
+    if st is not None:
+        # accumulator form: the sums are in (or now go to) the layer's backward accumulator, and the second pass finalises them itself
+        if not have:
+            st.produce(1)                                # (also clears sums that a consumer added for another gradient buffer)
+            _lib.call('fva_bn_silu_bwd_reduce_acc', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                      _p(st.buf[1]), s.M, Cout, _stream())
+        ba = _lib.BnBwdAcc(st.buf[1].data_ptr(), st.buf[0].data_ptr(), s.gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0)
+        _lib.call('fva_bn_silu_bwd_apply_acc', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                  C.byref(ba), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+        st.consumed(1)
+    else:
+        if have:
+            part, nb = fused[0], fused[1]
+        else:
+            nb = lib.fva_bn_bwd_blocks(code, s.M, Cout)
+            part = torch.empty((lib.fva_bn_partial_rows(nb), 2, Cout), dtype=torch.float32, device=dev)
+            _lib.call('fva_bn_silu_bwd_reduce', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                      _p(part), nb, s.M, Cout, _stream())
+        coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        _lib.call('fva_bn_bwd_finalize', _p(part), nb, part.shape[0], s.M, Cout, _p(s.gamma), _p(s.rstd), _p(dgamma), _p(dbeta), 0, _p(coef), _stream())
+        _lib.call('fva_bn_silu_bwd_apply', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
+                  _p(coef), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
+    del fused
     dw = torch.empty(s.wshape, dtype=torch.float32, device=dev)
     ws_bytes = lib.fva_conv_wgrad_workspace(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -157,6 +157,8 @@ typedef struct {
     const void* y;
     const float *scale, *shift, *mean, *rstd;
     float* partial;
+    int64_t* acc;        /* when not NULL the sums are ADDED to this accumulator (the producer layer's backward one, see "BatchNorm statistics
+                            WITHOUT a finalize launch") and `partial` is not used */
 } fva_bn_bwd_fuse;
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* fuse, void* stream);
@@ -233,11 +235,61 @@ int fva_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const f
  * border.  residual (optional) has the layout of z with border res_pad. */
 int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
                       int res_pad, void* z, int z_pad, int B, int H, int W, int C, void* stream);
+/* ---- BatchNorm statistics WITHOUT a finalize launch (round 4) ------------------------------------------------------------------
+ * The convolution's tiles ADD their per-channel partial sums into a fixed-point accumulator (two int64 words per sum: integer
+ * addition is associative, so the total is the same bits whatever order the tiles arrive in -- deterministic run to run) and the
+ * pass that consumes the statistics finalises them in its own prologue: every block computes mean / rstd / scale / shift of all
+ * channels once (the arithmetic of fva_bn_finalize), block 0 also writes them out for the backward pass and updates the running
+ * statistics (nn.BatchNorm2d in training mode, classfication/models/darknet53.py:11-12).  Replaces the 197 latency-bound finalize /
+ * pre-reduce launches of a YOLOv3 step, each a dependent step of the chain.
+ *   An accumulator is int64 [2][2][C] (words x sums x channels) and must be ZERO when its first producer runs.  A layer keeps one per
+ *   direction (forward: sums of y and y^2; backward: sums of dU and dU * xhat).  A consumer cannot zero the accumulator it reads (its
+ *   other blocks may not have read it yet), so each consumer zeroes the OTHER direction's (`zero`, may be NULL): the forward consumer
+ *   clears the backward sums of the previous step, the backward consumer clears the forward sums.  fva_bn_acc_finalize, the only
+ *   reader of its launch, zeroes both.  An accumulator nobody zeroed (a forward pass without backward) is the caller's to clear.
+ * Forward producers: fva_conv_fwd_acc (= fva_conv_fwd with the accumulator in place of the table), fva_conv1x1_fwd_apply_acc;
+ * forward consumers: fva_bn_silu_apply_acc, fva_conv1x1_fwd_apply_acc (of the block BEFORE it), fva_bn_acc_finalize.
+ * Backward producers: fva_conv_dgrad_bnstats with fva_bn_bwd_fuse::acc set, fva_bn_silu_bwd_reduce_acc; consumer: fva_bn_silu_bwd_apply_acc. */
+typedef struct {
+    int64_t* acc;
+    int64_t* zero;                          /* may be NULL: the other direction's accumulator, returned to zero by this launch */
+    const float *gamma, *beta;
+    float *running_mean, *running_var;      /* may be NULL */
+    int64_t* num_batches_tracked;           /* may be NULL */
+    float momentum, eps;
+    float *save_mean, *save_rstd, *scale, *shift;   /* outputs, [C] each */
+} fva_bn_fwd_acc;
+typedef struct {
+    int64_t* acc;
+    int64_t* zero;                          /* may be NULL */
+    const float* gamma;
+    float *dgamma, *dbeta;                  /* outputs (+= when accumulate) */
+    int32_t accumulate;
+} fva_bn_bwd_acc;
+int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, void* stream);
+int fva_bn_silu_apply_acc(int dtype, const void* y, const fva_bn_fwd_acc* acc, const void* residual, int res_pad, void* z, int z_pad,
+                          int B, int H, int W, int C, void* stream);
+/* The accumulator finalised by a small launch of its own (writes the four outputs, updates the running statistics, zeroes the
+ * accumulator): for a consumer that cannot do it in its prologue -- the thin tile of the fused 1x1 form, foreign code. */
+int fva_bn_acc_finalize(const fva_bn_fwd_acc* acc, int64_t M, int C, void* stream);
+/* fva_conv1x1_fwd_apply with this layer's statistics added to acc_out, and the block before described by `prev`: prev->acc != NULL: its
+ * statistics are finalised in this launch's prologue (Cout = 128: the wide tile; thinner layers run fva_bn_acc_finalize first, inside this
+ * call); prev->acc == NULL: prev->scale / prev->shift are final already. */
+int fva_conv1x1_fwd_apply_acc(const fva_conv_desc* d, const void* y_prev, const fva_bn_fwd_acc* prev, const void* residual, int32_t res_pad,
+                              void* z, const void* w_fwd, void* y, int64_t* acc_out, void* stream);
+
 /* Backward, pass 1: partial sums over pixels of dU = dz*silu'(u) and dU*xhat (u = y*scale+shift). */
 int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
                            const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks,
                            int64_t M, int C, void* stream);
 int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
+/* The accumulator forms of the two backward passes (see "BatchNorm statistics WITHOUT a finalize launch"): pass 1 adds its sums to
+ * acc; pass 2 takes dgamma, dbeta and its coefficients from the accumulator in its prologue (no fva_bn_bwd_finalize). */
+int fva_bn_silu_bwd_reduce_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                               const float* save_mean, const float* save_rstd, int64_t* acc, int64_t M, int C, void* stream);
+int fva_bn_silu_bwd_apply_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
+                              const float* save_mean, const float* save_rstd, const fva_bn_bwd_acc* acc, void* dy, int dy_pad,
+                              int B, int H, int W, int C, void* stream);
 /* Backward, finalize: dgamma, dbeta (+)= and the per-channel coefficients of pass 2.  partial: the table of
  * fva_bn_silu_bwd_reduce or of fva_conv_dgrad_bnstats, ALLOCATED with fva_bn_partial_rows(nblocks) rows: a long table (1024 rows
  * or more) is folded in parallel first, into doubles kept behind the nblocks rows the producer fills; partial_rows = the rows
