@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-CONV_CALLS = {'fva_conv_fwd': 'conv_fwd', 'fva_conv1x1_fwd_apply': 'conv_fwd', 'fva_conv_dgrad': 'conv_dgrad', 'fva_conv_dgrad_bnstats': 'conv_dgrad', 'fva_conv_wgrad': 'conv_wgrad',
+CONV_CALLS = {'fva_conv_fwd': 'conv_fwd', 'fva_conv_fwd_acc': 'conv_fwd', 'fva_conv1x1_fwd_apply': 'conv_fwd', 'fva_conv1x1_fwd_apply_acc': 'conv_fwd', 'fva_conv_dgrad': 'conv_dgrad', 'fva_conv_dgrad_bnstats': 'conv_dgrad', 'fva_conv_wgrad': 'conv_wgrad',
               'fva_head_fwd': 'conv_fwd'}
 
 

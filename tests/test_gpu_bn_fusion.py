@@ -159,8 +159,9 @@ def test_training_step_same_with_and_without_fused_statistics(key, surface):
     assert l0 == l1
     devs = np.array([rel(a, b) for a, b in zip(g1, g0)])
     worst = devs.max()
-    n_bn = n0['fva_bn_silu_bwd_reduce']
-    left = n1.get('fva_bn_silu_bwd_reduce', 0)
+    # (the layers that keep their statistics in accumulators -- all but the stem -- call the _acc form of the reduce pass)
+    n_bn = n0.get('fva_bn_silu_bwd_reduce', 0) + n0.get('fva_bn_silu_bwd_reduce_acc', 0)
+    left = n1.get('fva_bn_silu_bwd_reduce', 0) + n1.get('fva_bn_silu_bwd_reduce_acc', 0)
     print(f'{surface} {key}: stand-alone reduce launches {n_bn} -> {left}, fused dgrad launches {n1.get("fva_conv_dgrad_bnstats", 0)}, '
           f'gradient deviation (max-abs over the tensor scale): median {np.median(devs):.2e}, largest {worst:.2e}')
     # fp32: the two paths differ by the summation order of the statistics only.  bf16: that last-bit difference of a coefficient
