@@ -51,18 +51,18 @@ class PasteJob(C.Structure):
 
 
 class BnBwdFuse(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('y', 'scale', 'shift', 'mean', 'rstd', 'partial', 'acc')]
+    _fields_ = [(n, C.c_void_p) for n in ('y', 'scale', 'shift', 'mean', 'rstd', 'partial', 'acc')] + [('acc_replicas', C.c_int32)]
 
 
 class BnFwdAcc(C.Structure):
     """fva_bn_fwd_acc: BatchNorm statistics in a fixed-point accumulator, finalised by the consuming launch."""
-    _fields_ = [(n, C.c_void_p) for n in ('acc', 'zero', 'gamma', 'beta', 'running_mean', 'running_var', 'num_batches_tracked')] + \
+    _fields_ = [('acc', C.c_void_p), ('zero', C.c_void_p), ('replicas', C.c_int32)] + [(n, C.c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'num_batches_tracked')] + \
                [('momentum', C.c_float), ('eps', C.c_float)] + [(n, C.c_void_p) for n in ('save_mean', 'save_rstd', 'scale', 'shift')]
 
 
 class BnBwdAcc(C.Structure):
     """fva_bn_bwd_acc: the backward sums (dU, dU * xhat) in an accumulator, finalised by the second backward pass."""
-    _fields_ = [(n, C.c_void_p) for n in ('acc', 'zero', 'gamma', 'dgamma', 'dbeta')] + [('accumulate', C.c_int32)]
+    _fields_ = [('acc', C.c_void_p), ('zero', C.c_void_p), ('replicas', C.c_int32)] + [(n, C.c_void_p) for n in ('gamma', 'dgamma', 'dbeta')] + [('accumulate', C.c_int32)]
 
 
 class ColourJob(C.Structure):
@@ -96,10 +96,10 @@ PROTOTYPES = {
     'fva_conv_last_kernel': (C.c_char_p, []),
     'fva_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
     'fva_conv1x1_fwd_apply': (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
-    'fva_conv_fwd_acc': (_I, [_D, _P, _P, _P, _P, _P]),
+    'fva_conv_fwd_acc': (_I, [_D, _P, _P, _P, _P, _I, _P]),
     'fva_bn_acc_finalize': (_I, [C.POINTER(BnFwdAcc), _L, _I, _P]),
     'fva_bn_silu_apply_acc': (_I, [_I, _P, C.POINTER(BnFwdAcc), _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    'fva_conv1x1_fwd_apply_acc': (_I, [_D, _P, C.POINTER(BnFwdAcc), _P, _I, _P, _P, _P, _P, _P]),
+    'fva_conv1x1_fwd_apply_acc': (_I, [_D, _P, C.POINTER(BnFwdAcc), _P, _I, _P, _P, _P, _P, _I, _P]),
     'fva_conv_fwd_bnact': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     'fva_conv_stat_blocks': (_I, [_D]),
     'fva_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
@@ -125,7 +125,7 @@ PROTOTYPES = {
     'fva_bn_eval_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'fva_bn_silu_apply': (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'fva_bn_silu_bwd_reduce': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
-    'fva_bn_silu_bwd_reduce_acc': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'fva_bn_silu_bwd_reduce_acc': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     'fva_bn_bwd_blocks': (_I, [_I, _L, _I]),
     'fva_bn_bwd_finalize': (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P]),
     'fva_bn_silu_bwd_apply': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -163,7 +163,8 @@ __device__ __forceinline__ Vec16<T> ld_last(const T* p) {
 // to finish -- a ticket on `counter` -- puts accumulator and counter back to zero for the next step.  No finalize launch.
 struct BnFwdAcc {
     long long* acc;          // [2 words][2 sums][C]: the sums the producers added
-    long long* zero;         // may be null: another accumulator of 4 C words that this launch returns to zero (the layer's other direction)
+    long long* zero;         // may be null: another accumulator of the same size that this launch returns to zero (the layer's other direction)
+    int replicas;
     const float *gamma, *beta;
     float *running_mean, *running_var;
     long long* nbt;
@@ -174,27 +175,22 @@ struct BnFwdAcc {
 struct BnBwdAcc {
     long long* acc;          // sums of dU and dU * xhat
     long long* zero;
+    int replicas;
     const float *gamma, *rstd, *mean, *shift;
     float *dgamma, *dbeta;
     int accumulate;
     BnN n;
 };
-__device__ __forceinline__ void fx_zero(long long* acc, int C, int tid, int nthreads) {
-    if (acc != nullptr)
-        for (int i = tid; i < 4 * C; i += nthreads) acc[i] = 0;
-}
-
 // the accumulator finalised by a launch of its own: for consumers that cannot do it in their prologue (the thin fused 1x1 tile, foreign code)
 __global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnFwdAcc fin, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double s1, s2;
-        fx_load2(fin.acc, C, c, s1, s2);
+        fx_load2(fin.acc, C, fin.replicas, c, s1, s2);
         const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
         fin.save_mean[c] = k.mean; fin.save_rstd[c] = k.rstd; fin.scale[c] = k.scale; fin.shift[c] = k.shift;
         if (fin.running_mean) bn_running_update(fin.running_mean, fin.running_var, c, k, fin.n, fin.momentum);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FX_WORDS * fin.replicas; ++i) {
             fin.acc[(size_t)i * C + c] = 0;       // nobody else reads it: this launch is the only consumer
             if (fin.zero) fin.zero[(size_t)i * C + c] = 0;
         }
@@ -254,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
         const bool writer = blockIdx.x == 0;
         for (int c = threadIdx.x; c < h.C; c += 256) {
             double s1, s2;
-            fx_load2(fin.acc, h.C, c, s1, s2);
+            fx_load2(fin.acc, h.C, fin.replicas, c, s1, s2);
             const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
             fx_tab[c] = k.scale;
             fx_tab[h.C + c] = k.shift;
@@ -265,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
         }
         if (writer) {
             if (threadIdx.x == 0 && fin.nbt) *fin.nbt += 1;
-            fx_zero(fin.zero, h.C, threadIdx.x, 256);
+            fx_zero(fin.zero, h.C, fin.replicas, threadIdx.x, 256);
         }
         __syncthreads();
 #pragma unroll
@@ -315,7 +311,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ part, long long* acc, int64_t M, int C, int rows_per_block) {
+                                                            float* __restrict__ part, long long* acc, int replicas, int64_t M, int C, int rows_per_block) {
     constexpr int EPC = Vec16<T>::N;
     extern __shared__ float red[];  // [2][rpi][C]
     const int cpp = C / EPC, rpi = 256 / cpp;
@@ -351,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const int which = i / C, c = i - which * C;
         float s = 0.f;
         for (int k = 0; k < rpi; ++k) s += red[(which * rpi + k) * C + c];
-        if (acc != nullptr) fx_atomic_add(acc, C, which, c, s);
+        if (acc != nullptr) fx_atomic_add(fx_replica(acc, C, replicas), C, which, c, s);
         else part[((int64_t)blockIdx.x * 2 + which) * C + c] = s;
     }
 }
@@ -412,7 +408,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const bool writer = blockIdx.x == 0;
         for (int c = threadIdx.x; c < h.C; c += 256) {
             double s1, s2;
-            fx_load2(fin.acc, h.C, c, s1, s2);
+            fx_load2(fin.acc, h.C, fin.replicas, c, s1, s2);
             const BnBwdCoef q = bn_bwd_coef(s1, s2, fin.n, fin.gamma[c], rstd[c]);
             const BnBwdK k = bn_bwd_pack_coef(q.a, shift[c], mean[c], rstd[c], q.cb, q.cc);
             fx_tab[c] = scale[c];
@@ -425,7 +421,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 fin.dgamma[c] = fin.accumulate ? fin.dgamma[c] + q.dgamma : q.dgamma;
             }
         }
-        if (writer) fx_zero(fin.zero, h.C, threadIdx.x, 256);
+        if (writer) fx_zero(fin.zero, h.C, fin.replicas, threadIdx.x, 256);
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -671,7 +667,8 @@ static int fill_fwd_acc(const fva_bn_fwd_acc* a, int64_t M, BnFwdAcc& f, const c
     if (!a || !a->acc || !a->gamma || !a->beta || !a->save_mean || !a->save_rstd || !a->scale || !a->shift)
         return fva_fail(FVA_ERR_ARG, "%s: null pointer in the accumulator descriptor", who);
     if (a->zero == a->acc) return fva_fail(FVA_ERR_ARG, "%s: `zero` must be another accumulator (this one is still being read)", who);
-    f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.gamma = a->gamma; f.beta = a->beta;
+    if (!fva_replicas_ok(a->replicas)) return fva_fail(FVA_ERR_ARG, "%s: replicas = %d is not a power of two in 1..%d", who, a->replicas, FVA_BN_ACC_MAX_REPLICAS);
+    f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.replicas = a->replicas; f.gamma = a->gamma; f.beta = a->beta;
     f.running_mean = a->running_mean; f.running_var = a->running_var; f.nbt = (long long*)a->num_batches_tracked;
     f.momentum = a->momentum; f.eps = a->eps; f.n = bn_n((double)M);
     f.save_mean = a->save_mean; f.save_rstd = a->save_rstd; f.scale = a->scale; f.shift = a->shift;
@@ -726,9 +723,10 @@ int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C) {
 }
 
 static int bwd_reduce_impl(const char* who, int dtype, const void* dz, const void* y, const float* scale, const float* shift,
-                           const float* save_mean, const float* save_rstd, float* partial, int64_t* acc, int32_t nblocks, int64_t M, int C,
+                           const float* save_mean, const float* save_rstd, float* partial, int64_t* acc, int replicas, int32_t nblocks, int64_t M, int C,
                            void* stream) {
     int rc = check_chan(dtype, C, who);
+    if (acc && !fva_replicas_ok(replicas)) return fva_fail(FVA_ERR_ARG, "%s: replicas = %d is not a power of two in 1..%d", who, replicas, FVA_BN_ACC_MAX_REPLICAS);
     if (rc) return rc;
     const int epc = dtype == FVA_BF16 ? 8 : 4;
     const int cpp = C / epc;
@@ -741,10 +739,10 @@ static int bwd_reduce_impl(const char* who, int dtype, const void* dz, const voi
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblocks), dim3(256), smem, s, (const bf16_t*)dz, (const bf16_t*)y, scale,
-                           shift, save_mean, save_rstd, partial, (long long*)acc, M, C, rows);
+                           shift, save_mean, save_rstd, partial, (long long*)acc, replicas, M, C, rows);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblocks), dim3(256), smem, s, (const float*)dz, (const float*)y, scale,
-                           shift, save_mean, save_rstd, partial, (long long*)acc, M, C, rows);
+                           shift, save_mean, save_rstd, partial, (long long*)acc, replicas, M, C, rows);
     FVA_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     return FVA_OK;
 }
@@ -753,13 +751,13 @@ int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float
                            const float* save_mean, const float* save_rstd, float* partial, int32_t nblocks, int64_t M, int C,
                            void* stream) {
     if (!partial) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce: null pointer");
-    return bwd_reduce_impl("fva_bn_silu_bwd_reduce", dtype, dz, y, scale, shift, save_mean, save_rstd, partial, nullptr, nblocks, M, C, stream);
+    return bwd_reduce_impl("fva_bn_silu_bwd_reduce", dtype, dz, y, scale, shift, save_mean, save_rstd, partial, nullptr, 1, nblocks, M, C, stream);
 }
 
 int fva_bn_silu_bwd_reduce_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
-                               const float* save_mean, const float* save_rstd, int64_t* acc, int64_t M, int C, void* stream) {
+                               const float* save_mean, const float* save_rstd, int64_t* acc, int32_t replicas, int64_t M, int C, void* stream) {
     if (!acc) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_bwd_reduce_acc: null pointer");
-    return bwd_reduce_impl("fva_bn_silu_bwd_reduce_acc", dtype, dz, y, scale, shift, save_mean, save_rstd, nullptr, acc, 0, M, C, stream);
+    return bwd_reduce_impl("fva_bn_silu_bwd_reduce_acc", dtype, dz, y, scale, shift, save_mean, save_rstd, nullptr, acc, replicas, 0, M, C, stream);
 }
 
 int fva_bn_bwd_finalize(float* partial, int32_t nblocks, int32_t partial_rows, int64_t M, int C, const float* gamma, const float* save_rstd,
@@ -802,7 +800,8 @@ static int bwd_apply_impl(const char* who, int dtype, const void* dz, const void
         if (!a->acc || !a->gamma || !a->dgamma || !a->dbeta) return fva_fail(FVA_ERR_ARG, "%s: null pointer in the accumulator descriptor", who);
         if (a->zero == a->acc) return fva_fail(FVA_ERR_ARG, "%s: `zero` must be another accumulator (this one is still being read)", who);
         BnBwdAcc f = BnBwdAcc();
-        f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.gamma = a->gamma; f.dgamma = a->dgamma; f.dbeta = a->dbeta;
+        if (!fva_replicas_ok(a->replicas)) return fva_fail(FVA_ERR_ARG, "%s: replicas = %d is not a power of two in 1..%d", who, a->replicas, FVA_BN_ACC_MAX_REPLICAS);
+        f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.replicas = a->replicas; f.gamma = a->gamma; f.dgamma = a->dgamma; f.dbeta = a->dbeta;
         f.accumulate = a->accumulate; f.n = bn_n((double)B * H * W);
         const int grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 5 * C * 4;
         if (dtype == FVA_BF16)

@@ -99,43 +99,59 @@ __device__ __forceinline__ float silu_grad(float u) {
 // the tiles arrive; the accumulator is therefore a two-word FIXED-POINT number -- hi in units of 2^-8, lo in units of 2^-56, both int64
 // -- into which a partial is split exactly: integer addition is associative, so the sum is the same bits whatever the order
 // (deterministic run to run), and it carries every bit of a partial down to 2^-56 (an fp32 partial of magnitude >= 2^-32 exactly).
-// A non-finite partial poisons the accumulator (hi += 2^62): the finalised value reads NaN, as a floating-point sum would.
+// A non-finite partial is counted in a word of its own instead (the finalised sums of that channel then read NaN).
 struct FxSplit {
     long long hi, lo;
+    bool bad;
 };
 __device__ __forceinline__ FxSplit fx_split(float p) {
     FxSplit r;
-    if (!(__builtin_fabsf(p) < 1.0e15f)) {          // NaN, Inf, or beyond any plausible sum
-        r.hi = 1ll << 62;
-        r.lo = 0;
-        return r;
-    }
-    const double d = (double)p;
+    r.bad = !(__builtin_fabsf(p) < 1.0e15f);        // NaN, Inf, or beyond any plausible sum
+    const double d = r.bad ? 0.0 : (double)p;
     r.hi = __double2ll_rn(d * 256.0);
     const double rest = d - (double)r.hi * (1.0 / 256.0);         // exact: |rest| <= 2^-9 and no finer than ulp(p)
     r.lo = __double2ll_rn(rest * 72057594037927936.0);            // 2^56
     return r;
 }
-// Accumulator of one BatchNorm layer and direction: int64 acc[2 words (hi, lo)][2 sums][C] -- a wave that adds 32 channels of both sums
-// touches two contiguous 256-byte runs per word, the shape the memory-side atomic units take at full rate.  A layer has one for each
-// direction (forward: sums of y, y^2; backward: sums of dU, dU * xhat); the consumer of one direction returns the OTHER one to zero (its
-// own is still being read by its other blocks), so both are zero again when their producers next run -- graph replays included.
+// Accumulator of one BatchNorm layer and direction: int64 acc[replicas][FX_WORDS][C], words = {hi of sum 1, hi of sum 2, lo of sum 1,
+// lo of sum 2, count of non-finite partials} -- a wave that adds 32 channels of both sums touches two contiguous 256-byte runs per word,
+// the shape the memory-side atomic units take at full rate.  The atomics on ONE address are served one after the other (~10 ns each,
+// measured: a 12,800-tile launch ran 140 us longer than its table form), so layers with many tiles spread their adds over `replicas`
+// copies (a power of two; block b adds to copy b mod replicas) and the consumer adds the copies up -- still integers, still exact.
+// A layer has one accumulator per direction (forward: sums of y, y^2; backward: sums of dU, dU * xhat); the consumer of one direction
+// returns the OTHER one to zero (its own is still being read by its other blocks), so both are zero again when their producers next
+// run -- graph replays included.
+constexpr int FX_WORDS = FVA_BN_ACC_WORDS;
+inline bool fva_replicas_ok(int r) { return r >= 1 && r <= FVA_BN_ACC_MAX_REPLICAS && !(r & (r - 1)); }
+__device__ __forceinline__ long long* fx_replica(long long* acc, int C, int replicas) {
+    return acc + (size_t)(blockIdx.x & (unsigned)(replicas - 1)) * FX_WORDS * C;
+}
 __device__ __forceinline__ void fx_atomic_add(long long* acc, int C, int which, int c, float p) {
     const FxSplit s = fx_split(p);
+    if (s.bad) {                                       // poisons the channel: its finalised sums read NaN, as a floating-point sum would
+        atomicAdd((unsigned long long*)acc + (size_t)4 * C + c, 1ull);
+        return;
+    }
     atomicAdd((unsigned long long*)acc + (size_t)which * C + c, (unsigned long long)s.hi);
     atomicAdd((unsigned long long*)acc + (size_t)(2 + which) * C + c, (unsigned long long)s.lo);
 }
-__device__ __forceinline__ double fx_value(long long hi, long long lo) {
-    if (hi >= (1ll << 60) || hi <= -(1ll << 60)) return __builtin_nan("");
-    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 72057594037927936.0);
+__device__ __forceinline__ void fx_load2(const long long* acc, int C, int replicas, int c, double& s1, double& s2) {
+    long long h1 = 0, h2 = 0, l1 = 0, l2 = 0, bad = 0;
+    for (int r = 0; r < replicas; ++r) {
+        const long long* a = acc + (size_t)r * FX_WORDS * C;
+        h1 += a[c]; h2 += a[(size_t)C + c]; l1 += a[(size_t)2 * C + c]; l2 += a[(size_t)3 * C + c]; bad += a[(size_t)4 * C + c];
+    }
+    s1 = (double)h1 * (1.0 / 256.0) + (double)l1 * (1.0 / 72057594037927936.0);
+    s2 = (double)h2 * (1.0 / 256.0) + (double)l2 * (1.0 / 72057594037927936.0);
+    if (bad != 0) s1 = s2 = __builtin_nan("");
 }
-__device__ __forceinline__ void fx_load2(const long long* acc, int C, int c, double& s1, double& s2) {
-    s1 = fx_value(acc[c], acc[(size_t)2 * C + c]);
-    s2 = fx_value(acc[(size_t)C + c], acc[(size_t)3 * C + c]);
+__device__ __forceinline__ void fx_zero(long long* acc, int C, int replicas, int tid, int nthreads) {
+    if (acc != nullptr)
+        for (int i = tid; i < FX_WORDS * C * replicas; i += nthreads) acc[i] = 0;
 }
 // forward: batch statistics -> the coefficients of the apply pass.  Written to be cheap per channel (consumer kernels run it in their
-// prologue, every block): the pixel count comes as its reciprocal, and 1 / sqrt is v_rsq_f32 plus one Newton step (error < 1 ulp of
-// fp32) instead of a double-precision division and square root (~100 instructions each on this chip).
+// prologue, every block): the pixel count comes as its reciprocal, and 1 / sqrt is v_rsq_f64 plus one Newton step in double (then rounded
+// to fp32 once, like the division it replaces) instead of an IEEE double division and square root (~100 instructions each on this chip).
 struct BnN {
     double inv, unbias;      // 1 / count;  count / (count - 1): the factor of the unbiased variance for the running estimate
 };
@@ -155,10 +171,10 @@ __device__ __forceinline__ BnFwdCoef bn_fwd_coef(double s1, double s2, const BnN
     double var = __builtin_fma(s2, n.inv, -mean * mean);
     if (var < 0.0) var = 0.0;
     k.var = var;
-    const float x = (float)(var + (double)eps);
-    float r = __builtin_amdgcn_rsqf(x);
-    r = r * __builtin_fmaf(-0.5f * x * r, r, 1.5f);
-    k.rstd = r;
+    const double x = var + (double)eps;
+    double r = __builtin_amdgcn_rsq(x);                      // v_rsq_f64: ~2^-26 relative
+    r = __builtin_fma(0.5 * r, __builtin_fma(-x * r, r, 1.0), r);   // one Newton step: to the last bits of the double
+    k.rstd = (float)r;                                       // (fp32 training holds 1e-3 on the reference's loss curve only with rstd rounded once)
     k.mean = (float)mean;
     k.scale = gamma * k.rstd;
     k.shift = __builtin_fmaf(-k.mean, k.scale, beta);

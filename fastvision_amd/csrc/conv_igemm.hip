@@ -25,6 +25,7 @@ struct IgemmParams {
     const void* wt;
     void* out;
     float* stats;
+    int acc_rep, bnb_rep, ax_rep;   // replicas of stats_acc / bnb_acc / ax_acc (+ ax_zero): powers of two, see common.h
     long long* stats_acc;   // instead of the table `stats`: per-channel fixed-point accumulators acc[2][2][N] (common.h fx_atomic_add) that every tile ADDS to
     const float* bias;
     const float* scale;  // EPI_BNACT: per-output-channel affine (eval-mode BatchNorm folded in) before SiLU; NULL = 1 (bias only)
@@ -144,7 +145,7 @@ __device__ __forceinline__ void bnb_finish(const IgemmParams& p, float* red, con
         const int n = n0 + col;
         const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
         if (n < p.N) {
-            if (p.bnb_acc != nullptr) fx_atomic_add(p.bnb_acc, p.bnb_C, which, n - sub * p.bnb_C, t);
+            if (p.bnb_acc != nullptr) fx_atomic_add(fx_replica(p.bnb_acc, p.bnb_C, p.bnb_rep), p.bnb_C, which, n - sub * p.bnb_C, t);
             else *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
         }
     }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
             return;
         }
         double s1, s2;
-        fx_load2(p.ax_acc, p.C, c, s1, s2);
+        fx_load2(p.ax_acc, p.C, p.ax_rep, c, s1, s2);
         const BnFwdCoef k = bn_fwd_coef(s1, s2, p.ax_n, p.ax_gamma[c], p.ax_beta[c], p.ax_eps);
         sc_o = k.scale;
         sh_o = k.shift;
@@ -625,8 +626,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
         }
         if (AXT && p.ax_acc != nullptr && logical == 0) {     // the other direction's accumulator back to zero (this one is still being read)
             if (tid == 0 && p.ax_nbt) *p.ax_nbt += 1;
-            if (p.ax_zero != nullptr)
-                for (int i = tid; i < 4 * p.C; i += NT) p.ax_zero[i] = 0;
+            fx_zero(p.ax_zero, p.C, p.ax_rep, tid, NT);
         }
         ax_issue_b(0, 0);
     } else {
@@ -742,7 +742,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 #pragma unroll
                     for (int k = 0; k < WMc * 16; ++k) s += red[(which * WMc * 16 + k) * RP + col];
                     if (n0 + col < p.N) {
-                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        if (p.stats_acc != nullptr) fx_atomic_add(fx_replica(p.stats_acc, p.N, p.acc_rep), p.N, which, n0 + col, s);
                         else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                     }
                 }
@@ -780,7 +780,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
 #pragma unroll
                     for (int k = 0; k < WMc; ++k) s += red[(which * WMc + k) * BN + col];
                     if (n0 + col < p.N) {
-                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        if (p.stats_acc != nullptr) fx_atomic_add(fx_replica(p.stats_acc, p.N, p.acc_rep), p.N, which, n0 + col, s);
                         else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                     }
                 }
@@ -865,7 +865,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm_kernel(const
                     const int n = n0 + col;
                     const int sub = n >= p.bnb_C ? 1 : 0, per = p.N > p.bnb_C ? 2 : 1;
                     if (n < p.N) {
-                        if (p.bnb_acc != nullptr) fx_atomic_add(p.bnb_acc, p.bnb_C, which, n - sub * p.bnb_C, t);
+                        if (p.bnb_acc != nullptr) fx_atomic_add(fx_replica(p.bnb_acc, p.bnb_C, p.bnb_rep), p.bnb_C, which, n - sub * p.bnb_C, t);
                         else *(p.bnb_part + (((int64_t)(p.bnb_row0 + mblk) * per + sub) * 2 + which) * p.bnb_C + (n - sub * p.bnb_C)) = t;
                     }
                 }
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 64; ++k) t += red[(which * 64 + k) * RP + col];
                 if (col < p.N) {
-                    if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, col, t);
+                    if (p.stats_acc != nullptr) fx_atomic_add(fx_replica(p.stats_acc, p.N, p.acc_rep), p.N, which, col, t);
                     else *(p.stats + ((int64_t)tile * 2 + which) * p.N + col) = t;
                 }
             }
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmParams p, const 
 #pragma unroll
                     for (int i = 0; i < 32; ++i) s += red[(which * 32 + i) * RP + col];
                     if (n0 + col < p.N) {
-                        if (p.stats_acc != nullptr) fx_atomic_add(p.stats_acc, p.N, which, n0 + col, s);
+                        if (p.stats_acc != nullptr) fx_atomic_add(fx_replica(p.stats_acc, p.N, p.acc_rep), p.N, which, n0 + col, s);
                         else *(p.stats + ((int64_t)mblk * 2 + which) * p.N + n0 + col) = s;
                     }
                 }
@@ -2140,6 +2140,7 @@ static int setup_fwd(const fva_conv_desc* d, IgemmParams& p, const char* who) {
     const int k = d->ksize, s = d->stride;
     const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
     p = IgemmParams();
+    p.acc_rep = p.bnb_rep = p.ax_rep = 1;
     p.M = d->B * OH * OW;
     p.N = d->Cout;
     p.C = d->Cin;
@@ -2183,17 +2184,17 @@ int fva_conv_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, void*
 /* The forward apply pass of the block BEFORE a 1x1 convolution, fused into that convolution (igemm_kernel<..., AX>): see the header. */
 static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const fva_bn_fwd_acc* prev,
                                   const void* residual, int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial,
-                                  int64_t* acc_out, void* stream);
+                                  int64_t* acc_out, int32_t replicas_out, void* stream);
 
 int fva_conv1x1_fwd_apply(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const void* residual,
                           int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial, void* stream) {
     if (!scale || !shift) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply: null pointer");
-    return conv1x1_fwd_apply_impl(d, y_prev, scale, shift, nullptr, residual, res_pad, z, w_fwd, y, stats_partial, nullptr, stream);
+    return conv1x1_fwd_apply_impl(d, y_prev, scale, shift, nullptr, residual, res_pad, z, w_fwd, y, stats_partial, nullptr, 1, stream);
 }
 
 static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, const float* scale, const float* shift, const fva_bn_fwd_acc* prev,
                                   const void* residual, int32_t res_pad, void* z, const void* w_fwd, void* y, float* stats_partial,
-                                  int64_t* acc_out, void* stream) {
+                                  int64_t* acc_out, int32_t replicas_out, void* stream) {
     IgemmParams p;
     int rc = setup_fwd(d, p, "fva_conv1x1_fwd_apply");
     if (rc) return rc;
@@ -2208,10 +2209,11 @@ static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, co
     p.out = y;
     p.stats = stats_partial;
     p.stats_acc = (long long*)acc_out;
+    p.acc_rep = replicas_out;
     p.ax_y = y_prev; p.ax_res = residual; p.ax_z = z;
     p.ax_scale = scale; p.ax_shift = shift;
     if (prev) {
-        p.ax_acc = (long long*)prev->acc; p.ax_zero = (long long*)prev->zero;
+        p.ax_acc = (long long*)prev->acc; p.ax_zero = (long long*)prev->zero; p.ax_rep = prev->replicas;
         p.ax_gamma = prev->gamma; p.ax_beta = prev->beta; p.ax_rm = prev->running_mean; p.ax_rv = prev->running_var;
         p.ax_nbt = (long long*)prev->num_batches_tracked; p.ax_momentum = prev->momentum; p.ax_eps = prev->eps;
         p.ax_n = bn_n((double)p.M);
@@ -2223,36 +2225,39 @@ static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, co
                           : launch_one<bf16_t, 256, 64, EPI_STATS, 2, true>(p, (hipStream_t)stream);
 }
 
-int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, void* stream) {
+int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, int32_t replicas, void* stream) {
     IgemmParams p;
     int rc = setup_fwd(d, p, "fva_conv_fwd_acc");
     if (rc) return rc;
     if (!x || !w_fwd || !y || !acc) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_acc: null pointer");
+    if (!fva_replicas_ok(replicas)) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_acc: replicas = %d is not a power of two in 1..%d", replicas, FVA_BN_ACC_MAX_REPLICAS);
     if (d->Cout % 8) return fva_fail(FVA_ERR_ARG, "fva_conv_fwd_acc: Cout %d not a multiple of 8", d->Cout);
     p.in = x;
     p.wt = w_fwd;
     p.out = y;
     p.stats_acc = (long long*)acc;
+    p.acc_rep = replicas;
     FvaProfileSpan span(0 | (d->ksize << 8), 2.0 * p.M * (double)d->Cout * d->Cin * d->ksize * d->ksize, (hipStream_t)stream);
     if (use_pconv(d->dtype, d->ksize, d->stride, d->Cin, d->Cout, d->H, d->W)) return launch_pconv<EPI_STATS>(p, d->B, d->H, d->W, false, (hipStream_t)stream);
     return launch_igemm<EPI_STATS>(d->dtype, p, (hipStream_t)stream);
 }
 
 int fva_conv1x1_fwd_apply_acc(const fva_conv_desc* d, const void* y_prev, const fva_bn_fwd_acc* prev, const void* residual, int32_t res_pad,
-                              void* z, const void* w_fwd, void* y, int64_t* acc_out, void* stream) {
+                              void* z, const void* w_fwd, void* y, int64_t* acc_out, int32_t replicas_out, void* stream) {
     if (!prev || !prev->scale || !prev->shift || !acc_out) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null pointer");
+    if (!fva_replicas_ok(replicas_out)) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: replicas_out = %d is not a power of two in 1..%d", replicas_out, FVA_BN_ACC_MAX_REPLICAS);
     if (!prev->acc)          // the previous block's coefficients are given (finalised already: fva_bn_acc_finalize); only this layer's statistics accumulate
-        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
+        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, replicas_out, stream);
     if (!prev->gamma || !prev->beta || !prev->save_mean || !prev->save_rstd || prev->zero == prev->acc)
         return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null pointer in the accumulator descriptor");
+    if (!fva_replicas_ok(prev->replicas)) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: prev->replicas = %d is not a power of two in 1..%d", prev->replicas, FVA_BN_ACC_MAX_REPLICAS);
     if (!d) return fva_fail(FVA_ERR_ARG, "fva_conv1x1_fwd_apply_acc: null descriptor");
     if (!wide_tile(d->Cout)) {   // the thin tile has no room for the prologue (264 registers with it): a small launch finalises, the fused one takes the arrays
-        const int OH = d->H, OW = d->W;
-        const int rc = fva_bn_acc_finalize(prev, (int64_t)d->B * OH * OW, d->Cin, stream);
+        const int rc = fva_bn_acc_finalize(prev, (int64_t)d->B * d->H * d->W, d->Cin, stream);
         if (rc) return rc;
-        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
+        return conv1x1_fwd_apply_impl(d, y_prev, prev->scale, prev->shift, nullptr, residual, res_pad, z, w_fwd, y, nullptr, acc_out, replicas_out, stream);
     }
-    return conv1x1_fwd_apply_impl(d, y_prev, nullptr, nullptr, prev, residual, res_pad, z, w_fwd, y, nullptr, acc_out, stream);
+    return conv1x1_fwd_apply_impl(d, y_prev, nullptr, nullptr, prev, residual, res_pad, z, w_fwd, y, nullptr, acc_out, replicas_out, stream);
 }
 
 int fva_conv_fwd_bnact(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
@@ -2363,6 +2368,7 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
     const int OH = (d->H - 1) / s + 1, OW = (d->W - 1) / s + 1;
     FvaProfileSpan span(1 | (k << 8), 2.0 * d->B * OH * OW * (double)d->Cout * d->Cin * k * k, (hipStream_t)stream);
     IgemmParams p = IgemmParams();
+    p.acc_rep = p.bnb_rep = p.ax_rep = 1;
     p.in = dy;
     p.wt = w_dgrad;
     p.out = dx;
@@ -2378,6 +2384,8 @@ int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w
         p.bnb_y = f->y; p.bnb_scale = f->scale; p.bnb_shift = f->shift; p.bnb_mean = f->mean; p.bnb_rstd = f->rstd;
         p.bnb_part = f->partial;
         p.bnb_acc = (long long*)f->acc;
+        p.bnb_rep = f->acc ? f->acc_replicas : 1;
+        if (f->acc && !fva_replicas_ok(f->acc_replicas)) return fva_fail(FVA_ERR_ARG, "fva_conv_dgrad_bnstats: acc_replicas = %d is not a power of two in 1..%d", f->acc_replicas, FVA_BN_ACC_MAX_REPLICAS);
         p.bnb_row0 = 0;
         p.bnb_C = d->Cin;
     }

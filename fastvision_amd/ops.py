@@ -249,9 +249,9 @@ def _note_consumer(x):
     return src
 
 
-def _fuse_struct(src, part, acc=None):
+def _fuse_struct(src, part, acc=None, replicas=1):
     return _lib.BnBwdFuse(src.y.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr(), src.mean.data_ptr(), src.rstd.data_ptr(),
-                          None if part is None else part.data_ptr(), None if acc is None else acc.data_ptr())
+                          None if part is None else part.data_ptr(), None if acc is None else acc.data_ptr(), replicas)
 
 
 def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
@@ -263,7 +263,7 @@ def _dgrad(d, dy, wd, dx, addend_ptr, src, dtype):
             # the producer layer keeps its statistics in accumulators: the epilogue ADDS the sums to its backward one
             st = src.acc
             st.produce(1)
-            fs = _fuse_struct(src, None, st.buf[1])
+            fs = _fuse_struct(src, None, st.buf[1], st.replicas)
             _lib.call('fva_conv_dgrad_bnstats', C.byref(d), _p(dy), _p(wd), _p(dx), C.c_void_p(addend_ptr or 0), C.byref(fs), _stream())
             src.fused = (None, 0, dx.data_ptr(), dx)
             return
@@ -341,13 +341,16 @@ def set_bn_accumulators(on):
 
 
 class _AccState:
-    """The two accumulators of one BatchNorm layer (buf[0]: forward sums, buf[1]: backward sums) and what the host knows of them:
-    0 = zero, 1 = a producer has added to it, 2 = consumed (its sums are still there).  The normal sequence needs no clearing launch: each
-    direction's consumer zeroes the other direction's accumulator."""
-    __slots__ = ('buf', 'state')
+    """The two accumulators of one BatchNorm layer (buf[0]: forward sums, buf[1]: backward sums; int64 [replicas][5][C] each) and what
+    the host knows of them: 0 = zero, 1 = a producer has added to it, 2 = consumed (its sums are still there).  The normal sequence needs
+    no clearing launch: each direction's consumer zeroes the other direction's accumulator.  ``replicas``: one copy per 65536 output
+    pixels (a power of two, at most 32) -- the atomics on one address are served one after the other, ~10 ns each, and a layer at 320 x 320
+    runs 12800 tiles."""
+    __slots__ = ('buf', 'state', 'replicas')
 
-    def __init__(self, Cc, device):
-        self.buf = torch.zeros((2, 4 * Cc), dtype=torch.int64, device=device)
+    def __init__(self, Cc, M, device):
+        self.replicas = _replicas(M)
+        self.buf = torch.zeros((2, self.replicas * 5 * Cc), dtype=torch.int64, device=device)
         self.state = [0, 0]
 
     def produce(self, which):
@@ -360,11 +363,18 @@ class _AccState:
         self.state[1 - which] = 0           # the consumer returned the other direction's accumulator to zero
 
 
-def _acc_state(gamma):
+def _replicas(M):
+    r = 1
+    while r < 32 and r * 65536 < M:
+        r *= 2
+    return r
+
+
+def _acc_state(gamma, M):
     Cc = gamma.numel()
     st = getattr(gamma, '_fva_acc', None)
-    if st is None or st.buf.device != gamma.device or st.buf.shape[1] != 4 * Cc:
-        st = gamma._fva_acc = _AccState(Cc, gamma.device)
+    if st is None or st.buf.device != gamma.device or st.replicas != _replicas(M) or st.buf.shape[1] != st.replicas * 5 * Cc:
+        st = gamma._fva_acc = _AccState(Cc, M, gamma.device)
     return st
 
 
@@ -377,7 +387,7 @@ class _Fin:
     def desc(self, given=False):
         gamma, beta, bn, mean, rstd, scale, shift = self.keep
         opt = lambda t: None if t is None else t.data_ptr()
-        return _lib.BnFwdAcc(None if given else self.state.buf[0].data_ptr(), self.state.buf[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+        return _lib.BnFwdAcc(None if given else self.state.buf[0].data_ptr(), self.state.buf[1].data_ptr(), self.state.replicas, gamma.data_ptr(), beta.data_ptr(),
                              opt(bn.rm), opt(bn.rv), opt(bn.nbt), bn.momentum, bn.eps,
                              mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
 
@@ -433,7 +443,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
         if _BN_ACC[0] and gamma.is_cuda:
-            st = _acc_state(gamma)
+            st = _acc_state(gamma, M)
             st.produce(0)
             fin = _Fin(st, gamma, beta, bn, mean, rstd, scale, shift)
             stats = None
@@ -443,10 +453,10 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
             pf = pend['fin']
             if fin is not None:
                 # the block before: its accumulator is finalised by this launch (pf), or its coefficients are final already
-                prev = pf.desc() if pf is not None else _lib.BnFwdAcc(None, None, None, None, None, None, None, 0.0, 0.0, None, None,
+                prev = pf.desc() if pf is not None else _lib.BnFwdAcc(None, None, 1, None, None, None, None, None, 0.0, 0.0, None, None,
                                                                       pend['scale'].data_ptr(), pend['shift'].data_ptr())
                 _lib.call('fva_conv1x1_fwd_apply_acc', C.byref(d), _p(pend['y']), C.byref(prev), C.c_void_p(pend['res_ptr'] or 0),
-                          pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), _stream())
+                          pend['res_pad'], C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), st.replicas, _stream())
             else:
                 if pf is not None:
                     _lib.call('fva_bn_acc_finalize', C.byref(pf.desc()), M, Cin, _stream())
@@ -457,7 +467,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
             _DEFER['fused'] += 1
             pend = None
         elif fin is not None:
-            _lib.call('fva_conv_fwd_acc', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), _stream())
+            _lib.call('fva_conv_fwd_acc', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(st.buf[0]), st.replicas, _stream())
         else:
             _lib.call('fva_conv_fwd', C.byref(d), C.c_void_p(x_ptr), _p(wf), _p(y), _p(stats), _stream())
         if fin is None:
@@ -660,8 +670,8 @@ def conv_block_bwd(s, dz_ptr, need_dx, addend_ptr=None):
         if not have:
             st.produce(1)                                # (also clears sums that a consumer added for another gradient buffer)
             _lib.call('fva_bn_silu_bwd_reduce_acc', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
-                      _p(st.buf[1]), s.M, Cout, _stream())
-        ba = _lib.BnBwdAcc(st.buf[1].data_ptr(), st.buf[0].data_ptr(), s.gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0)
+                      _p(st.buf[1]), st.replicas, s.M, Cout, _stream())
+        ba = _lib.BnBwdAcc(st.buf[1].data_ptr(), st.buf[0].data_ptr(), st.replicas, s.gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0)
         _lib.call('fva_bn_silu_bwd_apply_acc', code, C.c_void_p(dz_ptr), _p(s.y), _p(s.scale), _p(s.shift), _p(s.mean), _p(s.rstd),
                   C.byref(ba), _p(dy), 1, d.B, s.OH, s.OW, Cout, _stream())
         st.consumed(1)

@@ -159,6 +159,7 @@ typedef struct {
     float* partial;
     int64_t* acc;        /* when not NULL the sums are ADDED to this accumulator (the producer layer's backward one, see "BatchNorm statistics
                             WITHOUT a finalize launch") and `partial` is not used */
+    int32_t acc_replicas;
 } fva_bn_bwd_fuse;
 int fva_conv_dgrad_bnstats(const fva_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend,
                            const fva_bn_bwd_fuse* fuse, void* stream);
@@ -242,17 +243,25 @@ int fva_bn_silu_apply(int dtype, const void* y, const float* scale, const float*
  * channels once (the arithmetic of fva_bn_finalize), block 0 also writes them out for the backward pass and updates the running
  * statistics (nn.BatchNorm2d in training mode, classfication/models/darknet53.py:11-12).  Replaces the 197 latency-bound finalize /
  * pre-reduce launches of a YOLOv3 step, each a dependent step of the chain.
- *   An accumulator is int64 [2][2][C] (words x sums x channels) and must be ZERO when its first producer runs.  A layer keeps one per
- *   direction (forward: sums of y and y^2; backward: sums of dU and dU * xhat).  A consumer cannot zero the accumulator it reads (its
- *   other blocks may not have read it yet), so each consumer zeroes the OTHER direction's (`zero`, may be NULL): the forward consumer
- *   clears the backward sums of the previous step, the backward consumer clears the forward sums.  fva_bn_acc_finalize, the only
- *   reader of its launch, zeroes both.  An accumulator nobody zeroed (a forward pass without backward) is the caller's to clear.
+ *   An accumulator is int64 [replicas][FVA_BN_ACC_WORDS][C] -- per channel the high and low words of the two sums and a count of
+ *   non-finite partials (a channel that received one finalises to NaN, as a floating-point sum would) -- and must be ZERO when its first
+ *   producer runs.  `replicas` (a power of two <= FVA_BN_ACC_MAX_REPLICAS; the same number for every producer and consumer of an
+ *   accumulator): atomics on one address are served one after the other (~10 ns each), so a layer whose convolution runs thousands of
+ *   tiles spreads them over several copies (block b adds to copy b mod replicas; about one copy per 65536 output pixels keeps the queue
+ *   per address below 5 us) and the consumer adds the copies up.  A layer keeps one accumulator per direction (forward: sums of y and
+ *   y^2; backward: sums of dU and dU * xhat), both with the same `replicas`.  A consumer cannot zero the accumulator it reads (its other
+ *   blocks may not have read it yet), so each consumer zeroes the OTHER direction's (`zero`, may be NULL): the forward consumer clears
+ *   the backward sums of the previous step, the backward consumer clears the forward sums.  fva_bn_acc_finalize, the only reader of
+ *   its launch, zeroes both.  An accumulator nobody zeroed (a forward pass without backward) is the caller's to clear.
  * Forward producers: fva_conv_fwd_acc (= fva_conv_fwd with the accumulator in place of the table), fva_conv1x1_fwd_apply_acc;
  * forward consumers: fva_bn_silu_apply_acc, fva_conv1x1_fwd_apply_acc (of the block BEFORE it), fva_bn_acc_finalize.
  * Backward producers: fva_conv_dgrad_bnstats with fva_bn_bwd_fuse::acc set, fva_bn_silu_bwd_reduce_acc; consumer: fva_bn_silu_bwd_apply_acc. */
+#define FVA_BN_ACC_WORDS 5
+#define FVA_BN_ACC_MAX_REPLICAS 32
 typedef struct {
     int64_t* acc;
     int64_t* zero;                          /* may be NULL: the other direction's accumulator, returned to zero by this launch */
+    int32_t replicas;
     const float *gamma, *beta;
     float *running_mean, *running_var;      /* may be NULL */
     int64_t* num_batches_tracked;           /* may be NULL */
@@ -262,11 +271,12 @@ typedef struct {
 typedef struct {
     int64_t* acc;
     int64_t* zero;                          /* may be NULL */
+    int32_t replicas;
     const float* gamma;
     float *dgamma, *dbeta;                  /* outputs (+= when accumulate) */
     int32_t accumulate;
 } fva_bn_bwd_acc;
-int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, void* stream);
+int fva_conv_fwd_acc(const fva_conv_desc* d, const void* x, const void* w_fwd, void* y, int64_t* acc, int32_t replicas, void* stream);
 int fva_bn_silu_apply_acc(int dtype, const void* y, const fva_bn_fwd_acc* acc, const void* residual, int res_pad, void* z, int z_pad,
                           int B, int H, int W, int C, void* stream);
 /* The accumulator finalised by a small launch of its own (writes the four outputs, updates the running statistics, zeroes the
@@ -276,7 +286,7 @@ int fva_bn_acc_finalize(const fva_bn_fwd_acc* acc, int64_t M, int C, void* strea
  * statistics are finalised in this launch's prologue (Cout = 128: the wide tile; thinner layers run fva_bn_acc_finalize first, inside this
  * call); prev->acc == NULL: prev->scale / prev->shift are final already. */
 int fva_conv1x1_fwd_apply_acc(const fva_conv_desc* d, const void* y_prev, const fva_bn_fwd_acc* prev, const void* residual, int32_t res_pad,
-                              void* z, const void* w_fwd, void* y, int64_t* acc_out, void* stream);
+                              void* z, const void* w_fwd, void* y, int64_t* acc_out, int32_t replicas_out, void* stream);
 
 /* Backward, pass 1: partial sums over pixels of dU = dz*silu'(u) and dU*xhat (u = y*scale+shift). */
 int fva_bn_silu_bwd_reduce(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
@@ -286,7 +296,7 @@ int32_t fva_bn_bwd_blocks(int dtype, int64_t M, int C);
 /* The accumulator forms of the two backward passes (see "BatchNorm statistics WITHOUT a finalize launch"): pass 1 adds its sums to
  * acc; pass 2 takes dgamma, dbeta and its coefficients from the accumulator in its prologue (no fva_bn_bwd_finalize). */
 int fva_bn_silu_bwd_reduce_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
-                               const float* save_mean, const float* save_rstd, int64_t* acc, int64_t M, int C, void* stream);
+                               const float* save_mean, const float* save_rstd, int64_t* acc, int32_t replicas, int64_t M, int C, void* stream);
 int fva_bn_silu_bwd_apply_acc(int dtype, const void* dz, const void* y, const float* scale, const float* shift,
                               const float* save_mean, const float* save_rstd, const fva_bn_bwd_acc* acc, void* dy, int dy_pad,
                               int B, int H, int W, int C, void* stream);

@@ -31,6 +31,8 @@ CASES = [
     (32, 128, 256, 40, 3, 1, torch.bfloat16),     # 8-phase 256 x 256 tile
     (2, 64, 128, 24, 3, 2, torch.float32),        # fp32 sibling
     (3, 64, 32, 20, 1, 1, torch.float32),
+    (8, 32, 64, 128, 3, 1, torch.bfloat16),       # 131072 output pixels: two replicas of the accumulator (patch kernel)
+    (16, 64, 32, 96, 1, 1, torch.bfloat16),       # 147456 pixels: four replicas (256 x 64 tile)
 ]
 
 
@@ -146,12 +148,13 @@ def test_fixed_point_sum_is_exact_and_poisoned_by_nan():
         if poison:
             x[1, 5, 5, 3] = float('nan')
         y = torch.empty(M, N, device=dev())
-        acc = torch.zeros(4 * N, dtype=torch.int64, device=dev())
-        other = torch.ones(4 * N, dtype=torch.int64, device=dev())
+        R = 4 if poison else 1               # (also: four replicas give the same sums as one)
+        acc = torch.zeros(R * 5 * N, dtype=torch.int64, device=dev())
+        other = torch.ones(R * 5 * N, dtype=torch.int64, device=dev())
         gamma, beta = torch.ones(N, device=dev()), torch.zeros(N, device=dev())
         mean, rstd, scale, shift = (torch.empty(N, device=dev()) for _ in range(4))
-        _lib.call('fva_conv_fwd_acc', C.byref(d), ops._p(x), ops._p(wf), ops._p(y), ops._p(acc), ops._stream())
-        fin = _lib.BnFwdAcc(acc.data_ptr(), other.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, None, 0.1, 1e-5,
+        _lib.call('fva_conv_fwd_acc', C.byref(d), ops._p(x), ops._p(wf), ops._p(y), ops._p(acc), R, ops._stream())
+        fin = _lib.BnFwdAcc(acc.data_ptr(), other.data_ptr(), R, gamma.data_ptr(), beta.data_ptr(), None, None, None, 0.1, 1e-5,
                             mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         _lib.call('fva_bn_acc_finalize', C.byref(fin), M, N, ops._stream())
         torch.cuda.synchronize()
