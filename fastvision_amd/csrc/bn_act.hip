@@ -182,20 +182,19 @@ struct BnBwdAcc {
     BnN n;
 };
 // the accumulator finalised by a launch of its own: for consumers that cannot do it in their prologue (the thin fused 1x1 tile, foreign code)
-__global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnFwdAcc fin, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) {
+__global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnFwdAcc fin, int C) {     // ONE block; dynamic LDS: FX_WORDS * C int64
+    extern __shared__ long long fx_words[];
+    fx_gather_lds(fin.acc, C, fin.replicas, fx_words, threadIdx.x, 256);
+    for (int c = threadIdx.x; c < C; c += 256) {
         double s1, s2;
-        fx_load2(fin.acc, C, fin.replicas, c, s1, s2);
+        fx_value2(fx_from_lds(fx_words, C, c), s1, s2);
         const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
         fin.save_mean[c] = k.mean; fin.save_rstd[c] = k.rstd; fin.scale[c] = k.scale; fin.shift[c] = k.shift;
         if (fin.running_mean) bn_running_update(fin.running_mean, fin.running_var, c, k, fin.n, fin.momentum);
-        for (int i = 0; i < FX_WORDS * fin.replicas; ++i) {
-            fin.acc[(size_t)i * C + c] = 0;       // nobody else reads it: this launch is the only consumer
-            if (fin.zero) fin.zero[(size_t)i * C + c] = 0;
-        }
     }
-    if (c == 0 && fin.nbt) *fin.nbt += 1;
+    fx_zero(fin.acc, C, fin.replicas, threadIdx.x, 256);          // nobody else reads it: this launch is the only consumer
+    fx_zero(fin.zero, C, fin.replicas, threadIdx.x, 256);
+    if (threadIdx.x == 0 && fin.nbt) *fin.nbt += 1;
 }
 
 // One padded row of z per block and step (grid = rows for the plain form; the accumulator form runs at most 2048 blocks that walk the rows,
@@ -248,9 +247,12 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const T* __restrict_
     float sc[EPC], sh[EPC];
     if constexpr (FIN) {
         const bool writer = blockIdx.x == 0;
+        long long* fx_words = (long long*)(fx_tab + 2 * h.C);      // replicas > 1: [FX_WORDS][C] behind the table
+        if (fin.replicas > 1) fx_gather_lds(fin.acc, h.C, fin.replicas, fx_words, threadIdx.x, 256);
         for (int c = threadIdx.x; c < h.C; c += 256) {
             double s1, s2;
-            fx_load2(fin.acc, h.C, fin.replicas, c, s1, s2);
+            if (fin.replicas > 1) fx_value2(fx_from_lds(fx_words, h.C, c), s1, s2);
+            else fx_load2(fin.acc, h.C, 1, c, s1, s2);
             const BnFwdCoef k = bn_fwd_coef(s1, s2, fin.n, fin.gamma[c], fin.beta[c], fin.eps);
             fx_tab[c] = k.scale;
             fx_tab[h.C + c] = k.shift;
@@ -406,9 +408,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     float sc[EPC], sh[EPC], ka[EPC], k1[EPC], k2[EPC];
     if constexpr (FIN) {
         const bool writer = blockIdx.x == 0;
+        long long* fx_words = (long long*)(fx_tab + 5 * h.C + (h.C & 1));     // replicas > 1: [FX_WORDS][C] behind the table, 8-byte aligned
+        if (fin.replicas > 1) fx_gather_lds(fin.acc, h.C, fin.replicas, fx_words, threadIdx.x, 256);
         for (int c = threadIdx.x; c < h.C; c += 256) {
             double s1, s2;
-            fx_load2(fin.acc, h.C, fin.replicas, c, s1, s2);
+            if (fin.replicas > 1) fx_value2(fx_from_lds(fx_words, h.C, c), s1, s2);
+            else fx_load2(fin.acc, h.C, 1, c, s1, s2);
             const BnBwdCoef q = bn_bwd_coef(s1, s2, fin.n, fin.gamma[c], rstd[c]);
             const BnBwdK k = bn_bwd_pack_coef(q.a, shift[c], mean[c], rstd[c], q.cb, q.cc);
             fx_tab[c] = scale[c];
@@ -680,7 +685,8 @@ int fva_bn_acc_finalize(const fva_bn_fwd_acc* acc, int64_t M, int C, void* strea
     const int rc = fill_fwd_acc(acc, M, f, "fva_bn_acc_finalize");
     if (rc) return rc;
     if (C < 1 || M < 1) return fva_fail(FVA_ERR_ARG, "fva_bn_acc_finalize: bad size");
-    hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, f, C);
+    if (C > 2048) return fva_fail(FVA_ERR_ARG, "fva_bn_acc_finalize: C = %d > 2048", C);
+    hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3(1), dim3(256), FX_WORDS * C * 8, (hipStream_t)stream, f, C);
     FVA_LAUNCH_CHECK("bn_acc_finalize_kernel");
     return FVA_OK;
 }
@@ -697,7 +703,7 @@ int fva_bn_silu_apply_acc(int dtype, const void* y, const fva_bn_fwd_acc* acc, c
     if (h.total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply_acc: tensor too large");
     if ((h.cpp & (h.cpp - 1)) || h.cpp > 256) return fva_fail(FVA_ERR_ARG, "fva_bn_silu_apply_acc: C=%d must be a power of two (<= 256 chunks)", C);
     hipStream_t s = (hipStream_t)stream;
-    const int nrows = B * h.Hp, grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 2 * C * 4;
+    const int nrows = B * h.Hp, grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 2 * C * 4 + (f.replicas > 1 ? FX_WORDS * C * 8 : 0);
     if (dtype == FVA_BF16)
         hipLaunchKernelGGL((bn_silu_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, (const bf16_t*)y, nullptr, nullptr,
                            (const bf16_t*)residual, res_pad, (bf16_t*)z, h, f, nrows);
@@ -803,7 +809,7 @@ static int bwd_apply_impl(const char* who, int dtype, const void* dz, const void
         if (!fva_replicas_ok(a->replicas)) return fva_fail(FVA_ERR_ARG, "%s: replicas = %d is not a power of two in 1..%d", who, a->replicas, FVA_BN_ACC_MAX_REPLICAS);
         f.acc = (long long*)a->acc; f.zero = (long long*)a->zero; f.replicas = a->replicas; f.gamma = a->gamma; f.dgamma = a->dgamma; f.dbeta = a->dbeta;
         f.accumulate = a->accumulate; f.n = bn_n((double)B * H * W);
-        const int grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = 5 * C * 4;
+        const int grid = nrows < ACC_GRID ? nrows : ACC_GRID, smem = (5 * C + (C & 1)) * 4 + (f.replicas > 1 ? FX_WORDS * C * 8 : 0);
         if (dtype == FVA_BF16)
             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), smem, s, (const bf16_t*)dz, (const bf16_t*)y,
                                scale, shift, save_mean, save_rstd, nullptr, (bf16_t*)dy, h, nrows, f);

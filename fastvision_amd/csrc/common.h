@@ -145,6 +145,43 @@ __device__ __forceinline__ void fx_load2(const long long* acc, int C, int replic
     s2 = (double)h2 * (1.0 / 256.0) + (double)l2 * (1.0 / 72057594037927936.0);
     if (bad != 0) s1 = s2 = __builtin_nan("");
 }
+// The consumer's view of one channel: the four words and the poison count, summed over the replicas.
+struct FxSums {
+    long long h1, h2, l1, l2, bad;
+};
+__device__ __forceinline__ void fx_value2(const FxSums& w, double& s1, double& s2) {
+    s1 = (double)w.h1 * (1.0 / 256.0) + (double)w.l1 * (1.0 / 72057594037927936.0);
+    s2 = (double)w.h2 * (1.0 / 256.0) + (double)w.l2 * (1.0 / 72057594037927936.0);
+    if (w.bad != 0) s1 = s2 = __builtin_nan("");
+}
+// All channels of a replicated accumulator added up by the whole block: lds = long long [FX_WORDS][C]; every thread fetches its share of
+// the replicas * FX_WORDS * C words (independent loads, all in flight together -- a thread walking the replicas of its own channel pays
+// one memory round trip per replica) and adds it with an LDS integer atomic.  Ends with a barrier.
+__device__ __forceinline__ void fx_gather_lds(const long long* acc, int C, int replicas, long long* lds, int tid, int nthreads) {
+    const int n = FX_WORDS * C;
+    for (int i = tid; i < n; i += nthreads) lds[i] = 0;
+    __syncthreads();
+    const int total = n * replicas;
+    for (int j0 = tid; j0 < total; j0 += nthreads * 8) {      // eight loads in flight per thread, then eight adds: no branch between a load and the next
+        long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * nthreads;
+            v[u] = j < total ? acc[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * nthreads;
+            if (j < total) atomicAdd((unsigned long long*)(lds + (j - (j / n) * n)), (unsigned long long)v[u]);
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ FxSums fx_from_lds(const long long* lds, int C, int c) {
+    FxSums w;
+    w.h1 = lds[c]; w.h2 = lds[C + c]; w.l1 = lds[2 * C + c]; w.l2 = lds[3 * C + c]; w.bad = lds[4 * C + c];
+    return w;
+}
 __device__ __forceinline__ void fx_zero(long long* acc, int C, int replicas, int tid, int nthreads) {
     if (acc != nullptr)
         for (int i = tid; i < FX_WORDS * C * replicas; i += nthreads) acc[i] = 0;
