@@ -406,6 +406,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     // lane-constant channel chunk (cpp divides 256): dY = a*dU + k1*y + k2 with k1 = coefB*rstd, k2 = coefC - k1*mean
     const int cc = threadIdx.x & cmask;
     float sc[EPC], sh[EPC], ka[EPC], k1[EPC], k2[EPC];
+    Vec16<T> g[U], v[U];
+    bool ok[U];
+    int64_t m0 = 0;
+    auto set_row = [&](int row) -> bool {       // false: a border row
+        const int b = row / h.Hp, yy = row - b * h.Hp - h.pad;
+        m0 = ((int64_t)b * h.H + yy) * h.W;
+        return yy >= 0 && yy < h.H;
+    };
+    auto load = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            const int xx = (i >> cshift) - h.pad;
+            ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
+            const int64_t off = (m0 + (ok[u] ? xx : 0)) * h.C + cc * EPC;
+            g[u] = ld_last<T>(dz + off);
+            v[u] = ld_last<T>(y + off);
+        }
+    };
+    // FIN: the first row's operands are requested before the prologue and stay in flight across its (cold) accumulator reads
+    bool first = FIN && (int)blockIdx.x < nrows && set_row(blockIdx.x) && (int)threadIdx.x < row_chunks;
+    if (first) load(threadIdx.x);
     if constexpr (FIN) {
         const bool writer = blockIdx.x == 0;
         long long* fx_words = (long long*)(fx_tab + 5 * h.C + (h.C & 1));     // replicas > 1: [FX_WORDS][C] behind the table, 8-byte aligned
@@ -445,11 +467,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             k2[e] = k.k2;
         }
     }
-    // one padded row per block
+    // one padded row per block and step
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int b = row / h.Hp, yp = row - b * h.Hp;
-        const int yy = yp - h.pad;
-        const bool row_in = yy >= 0 && yy < h.H;
+        const bool row_in = set_row(row);
         T* orow = dy + (int64_t)row * row_chunks * EPC;
         if (!row_in) {
             Vec16<T> zero;
@@ -458,19 +478,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             for (int i = threadIdx.x; i < row_chunks; i += 256) *(Vec16<T>*)(orow + (int64_t)i * EPC) = zero;
             continue;
         }
-        const int64_t m0 = ((int64_t)b * h.H + yy) * h.W;
         for (int i0 = threadIdx.x; i0 < row_chunks; i0 += 256 * U) {
-            Vec16<T> g[U], v[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * 256;
-                const int xx = (i >> cshift) - h.pad;
-                ok[u] = i < row_chunks && xx >= 0 && xx < h.W;
-                const int64_t off = (m0 + (ok[u] ? xx : 0)) * h.C + cc * EPC;
-                g[u] = ld_last<T>(dz + off);
-                v[u] = ld_last<T>(y + off);
-            }
+            if (!first) load(i0);
+            first = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = i0 + u * 256;
@@ -589,7 +599,7 @@ __global__ void cast_nhwc_kernel(const TS* __restrict__ src, int spad, TD* __res
     }
 }
 
-constexpr int ACC_GRID = 2048;    // blocks of the accumulator forms of the apply kernels (8 per CU): each walks rows, its prologue paid once
+constexpr int ACC_GRID = 2048;    // blocks of the accumulator forms of the apply kernels: each walks rows, its prologue paid once (1280 ... one block per row measured alike)
 
 inline int stream_grid(int64_t items) {
     int64_t g = (items + 255) / 256;

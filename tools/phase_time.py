@@ -47,6 +47,6 @@ def measure(label):
 
 
 for rep in range(2):
-    for acc in (False, True):
+    for acc in ((True,) if os.environ.get('FVA_PHASE_ON_ONLY') else (False, True)):
         ops.set_bn_accumulators(acc)
         measure('accumulators %s' % ('on' if acc else 'off'))
