@@ -39,6 +39,14 @@ def test_argument_errors_are_reported_not_crashed(built):
     assert lib.fva_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None) == -1
     with pytest.raises(RuntimeError):
         built.call('fva_adam_step', None, None, 0, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None)
+    # the accumulator forms: a replica count that is no power of two (or beyond FVA_BN_ACC_MAX_REPLICAS), a consumer asked to zero the accumulator it reads
+    d = built.ConvDesc(1, 2, 8, 8, 64, 64, 3, 1, 1, 1)
+    for bad in (0, 3, 64):
+        assert lib.fva_conv_fwd_acc(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), bad, None) == -1
+        assert b'replicas' in lib.fva_last_error()
+    fin = built.BnFwdAcc(64, 64, 1, 16, 16, None, None, None, 0.1, 1e-5, 16, 16, 16, 16)
+    assert lib.fva_bn_silu_apply_acc(1, C.c_void_p(16), C.byref(fin), None, 0, C.c_void_p(16), 1, 2, 8, 8, 64, None) == -1
+    assert b'another accumulator' in lib.fva_last_error()
 
 
 def test_modules_mirror_reference_keys_and_seeded_init():
@@ -305,3 +313,30 @@ def test_rpn_sample_refuses_a_permutation_that_does_not_fit():
         rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([1, 0, 2]), torch.tensor([3, 1, 0]))       # 3 indexes past the 3 candidates
     with pytest.raises(ValueError, match='positive permutation'):
         rpn_ops.rpn_sample(lab, 2, 2, torch.tensor([-1, 0, 2]), torch.tensor([2, 1, 0]))      # negative index
+
+
+def test_accumulator_bookkeeping_of_the_batchnorm_statistics():
+    """Host side of the accumulator form of the BatchNorm statistics (ops._AccState): one replica per 65536 output pixels (a power of two,
+    at most 32 = FVA_BN_ACC_MAX_REPLICAS), five words per channel and replica; a producer that finds its accumulator not zero clears it
+    first, each direction's consumer leaves the OTHER direction marked zero (it zeroed it on the device) and its own marked consumed."""
+    from fastvision_amd import ops
+    assert [ops._replicas(m) for m in (1, 65536, 65537, 204800, 819200, 3276800, 10 ** 9)] == [1, 1, 2, 4, 16, 32, 32]
+    st = ops._AccState(64, 819200, torch.device('cpu'))
+    assert st.replicas == 16 and tuple(st.buf.shape) == (2, 16 * 5 * 64) and st.buf.dtype == torch.int64 and not st.buf.any()
+    st.produce(0)                                   # forward producer: clean -> produced, nothing to clear
+    assert st.state == [1, 0]
+    st.buf[0].fill_(7)                              # (what the tiles add)
+    st.buf[1].fill_(9)                              # (backward sums of the previous step)
+    st.consumed(0)                                  # the forward consumer zeroes the backward accumulator ON THE DEVICE; the host only notes it
+    assert st.state == [2, 0]
+    st.produce(1)                                   # backward producer: marked zero -> no clearing launch
+    assert st.state == [2, 1] and st.buf[1].eq(9).all()
+    st.consumed(1)
+    assert st.state == [0, 2]
+    st.produce(1)                                   # a second backward without a forward in between: the stale sums are cleared first
+    assert st.state == [0, 1] and not st.buf[1].any()
+    # the header's constants
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'fastvision_amd.h')).read()
+    assert int(re.search(r'#define FVA_BN_ACC_WORDS (\d+)', hdr).group(1)) == 5
+    assert int(re.search(r'#define FVA_BN_ACC_MAX_REPLICAS (\d+)', hdr).group(1)) == 32
