@@ -384,10 +384,10 @@ class _Fin:
     def __init__(self, state, gamma, beta, bn, mean, rstd, scale, shift):
         self.state, self.keep = state, (gamma, beta, bn, mean, rstd, scale, shift)
 
-    def desc(self, given=False):
+    def desc(self):
         gamma, beta, bn, mean, rstd, scale, shift = self.keep
         opt = lambda t: None if t is None else t.data_ptr()
-        return _lib.BnFwdAcc(None if given else self.state.buf[0].data_ptr(), self.state.buf[1].data_ptr(), self.state.replicas, gamma.data_ptr(), beta.data_ptr(),
+        return _lib.BnFwdAcc(self.state.buf[0].data_ptr(), self.state.buf[1].data_ptr(), self.state.replicas, gamma.data_ptr(), beta.data_ptr(),
                              opt(bn.rm), opt(bn.rv), opt(bn.nbt), bn.momentum, bn.eps,
                              mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
 
