@@ -586,7 +586,7 @@ def main():
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         d = summ[dom]
-        kernel_name = {'conv_fwd': 'igemm8_kernel / igemm_kernel <EPI_STATS>: implicit-GEMM convolution, forward launches (fva_conv_fwd)',
+        kernel_name = {'conv_fwd': 'igemm8_kernel / igemm_kernel <EPI_STATS>: implicit-GEMM convolution, forward launches (fva_conv_fwd[_acc]; the 13 1x1 launches that also carry the apply pass of the block before them are a class of their own: kernels.conv_fwd_fused)',
                        'conv_dgrad': 'igemm_kernel<EPI_PLAIN> (fva_conv_dgrad)',
                        'conv_wgrad': 'wgrad_kernel (+reduce) (fva_conv_wgrad)'}[dom]
         traffic = None

@@ -2220,7 +2220,7 @@ static int conv1x1_fwd_apply_impl(const fva_conv_desc* d, const void* y_prev, co
         p.ax_save_mean = prev->save_mean; p.ax_save_rstd = prev->save_rstd; p.ax_scale_out = prev->scale; p.ax_shift_out = prev->shift;
     }
     p.ax_pad = d->in_pad; p.ax_res_pad = res_pad; p.ax_H = d->H; p.ax_W = d->W;
-    FvaProfileSpan span(0 | (1 << 8), 2.0 * p.M * (double)d->Cout * d->Cin, (hipStream_t)stream);
+    FvaProfileSpan span(3 | (1 << 8), 2.0 * p.M * (double)d->Cout * d->Cin, (hipStream_t)stream);   // class 3: a forward launch that also carries an apply pass
     return wide_tile(p.N) ? launch_one<bf16_t, 128, 128, EPI_STATS, 2, true>(p, (hipStream_t)stream)
                           : launch_one<bf16_t, 256, 64, EPI_STATS, 2, true>(p, (hipStream_t)stream);
 }

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-CONV_CALLS = {'fva_conv_fwd': 'conv_fwd', 'fva_conv_fwd_acc': 'conv_fwd', 'fva_conv1x1_fwd_apply': 'conv_fwd', 'fva_conv1x1_fwd_apply_acc': 'conv_fwd', 'fva_conv_dgrad': 'conv_dgrad', 'fva_conv_dgrad_bnstats': 'conv_dgrad', 'fva_conv_wgrad': 'conv_wgrad',
+CONV_CALLS = {'fva_conv_fwd': 'conv_fwd', 'fva_conv_fwd_acc': 'conv_fwd', 'fva_conv1x1_fwd_apply': 'conv_fwd_fused', 'fva_conv1x1_fwd_apply_acc': 'conv_fwd_fused', 'fva_conv_dgrad': 'conv_dgrad', 'fva_conv_dgrad_bnstats': 'conv_dgrad', 'fva_conv_wgrad': 'conv_wgrad',
               'fva_head_fwd': 'conv_fwd'}
 
 
@@ -130,12 +130,13 @@ class PyKernelTimer:
 
 class KernelTimer:
     """Spans recorded inside the library around fva_conv_fwd / fva_head_fwd / fva_conv_fwd_bnact (class conv_fwd),
-    fva_conv_dgrad (conv_dgrad) and fva_conv_wgrad incl. its reduce (conv_wgrad).  ``pool`` = number of calls expected
+    fva_conv_dgrad (conv_dgrad), fva_conv_wgrad incl. its reduce (conv_wgrad) and fva_conv1x1_fwd_apply[_acc] (conv_fwd_fused: a 1x1
+    forward launch that also carries the BatchNorm + SiLU apply pass of the block before it; its FLOPs are the convolution's only).  ``pool`` = number of calls expected
     while armed (more are simply not timed); the events are created in __enter__, before anything the caller times."""
-    CLASSES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad')
+    CLASSES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_fwd_fused')
 
     def __init__(self, pool=4096, classes=None, stride=1):
-        """classes: bracket only these (default all three); stride: of their calls, only every stride-th one.  A span costs
+        """classes: bracket only these (default all); stride: of their calls, only every stride-th one.  A span costs
         two event packets on the stream and ~7 us of GPU time, so a throughput run brackets a sample of the class it reports."""
         self.pool = int(pool)
         self.spans = None

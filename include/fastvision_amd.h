@@ -45,7 +45,8 @@ int fva_version(void);
 /* Live timing of the MFMA convolution entry points with HIP events on their launch stream, taken inside the library (no
  * per-call host work in the caller).  fva_profile_start(max_spans) creates the events -- call it OUTSIDE the region being
  * timed -- and arms the spans; fva_profile_stop() synchronises the device, disarms and returns the number of spans with
- * cls (low byte: 0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce; bits 8..: the layer's kernel size), algorithmic
+ * cls (low byte: 0 forward incl. head, 1 dgrad, 2 wgrad incl. its reduce, 3 a forward launch that also carries the apply pass of the
+ * block before it (fva_conv1x1_fwd_apply[_acc]; FLOPs = the convolution's); bits 8..: the layer's kernel size), algorithmic
  * FLOPs and elapsed milliseconds of each.
  * fva_profile_classes(mask, stride) restricts the spans to the classes whose bit is set and, of those calls, to every
  * stride-th one (default: all classes, stride 1).  A span costs two event packets on the stream and the kernels on either
