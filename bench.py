@@ -616,6 +616,13 @@ def main():
                          'frac': round(d['tflops'] / peak, 4), 'traffic': traffic,
                          'launches_per_step': probe_summ[dom]['launches'] // probe_steps, 'launches_timed': d['launches'],
                          'sampling': roof_how,
+                         # rounds 1-3 pooled ALL forward launches; the 13 launches that now also carry an apply pass left that class in
+                         # round 4 -- the same pooled figure, from the probe pass, for comparison across rounds
+                         'pooled_with_fused_launches': (lambda a, b: None if b is None else {
+                             'achieved': round((a['flop_total'] + b['flop_total']) / ((a['ms_total'] + b['ms_total']) * 1e-3) / 1e12, 2),
+                             'frac': round((a['flop_total'] + b['flop_total']) / ((a['ms_total'] + b['ms_total']) * 1e-3) / 1e12 / peak, 4),
+                             'launches_per_step': (a['launches'] + b['launches']) // probe_steps,
+                             'note': 'probe pass (exclusive), plain + fused forward launches'})(probe_summ[dom], probe_summ.get('conv_fwd_fused')) if dom == 'conv_fwd' else None,
                          'avg_launch_ms': round(d['ms_avg'], 4), 'gflop_per_launch': round(d['flop_per_launch'] / 1e9, 3),
                          'ms_per_step': round(probe_summ[dom]['ms_total'] / probe_steps, 3),
                          'shader_clock_mhz_under_load': None if clock_mhz is None else round(clock_mhz),
