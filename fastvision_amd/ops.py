@@ -324,13 +324,15 @@ def flush_pending_apply():
 
 # ---- BatchNorm statistics without a launch of their own ------------------------------------------------------------------------------
 # The table form (every tile of the convolution stores its partial sums, fva_bn_finalize folds them) costs one or two small launches
-# per layer, each a dependent step of the chain: 72 layers x (pre-reduce +) finalize = 2 ms of a 28 ms step (measured by leaving them out,
+# per layer and direction, each a dependent step of the chain: 197 launches = 2 ms of a 28 ms step (measured by leaving them out,
 # profiles/r04_experiments.md).  In the accumulator form every tile ADDS its partial sums to a per-layer fixed-point accumulator (two
 # int64 words per sum: integer addition is associative, so the result does not depend on the order of the atomics and stays
-# run-to-run bit-identical), and the launch that consumes the statistics -- the apply pass, or the fused 1x1 convolution that carries it --
-# turns them into scale / shift in its prologue, updates the running statistics from one block and returns the accumulator to zero.
-# The accumulator lives on the BatchNorm weight (one per layer, allocated once, zero between uses); `dirty` tracks a producer whose
-# consumer never ran (an exception in between): the next producer then clears it first.
+# run-to-run bit-identical), and the launch that consumes the statistics -- the apply pass, the fused 1x1 convolution that carries it,
+# the second backward pass -- turns them into its coefficients in its prologue; block 0 also writes mean / rstd / scale / shift (or
+# dgamma / dbeta) and updates the running statistics.  The accumulators hang on the BatchNorm weight (one per layer and direction,
+# allocated once); who returns which to zero, and what the host tracks about it, is _AccState's docstring.  The stem (its own kernels)
+# and eval mode keep the table form / the running statistics; FVA_BN_ACC=0 selects the table form everywhere (what the accumulator form
+# is tested against, tests/test_gpu_bn_acc.py).
 _BN_ACC = [os.environ.get('FVA_BN_ACC', '1') != '0']
 
 
