@@ -157,12 +157,12 @@ __device__ __forceinline__ Vec16<T> ld_last(const T* p) {
 #ifndef FVA_BN_UNROLL
 #define FVA_BN_UNROLL 2      // measured 1 / 2 / 4 (tools/bench_bn.py, sum over the layer shapes): fwd 348 / 337 / 340 us, bwd 514 / 506 / 504 us
 #endif
-// FIN: the batch statistics arrive as fixed-point accumulators that the producing convolution's tiles added to (common.h); every block
-// finalises the channels it needs in its prologue (the arithmetic of bn_finalize_kernel, so all blocks agree to the bit), the first
-// interior block also writes mean / rstd / scale / shift for the backward pass and updates the running statistics, and the last block
-// to finish -- a ticket on `counter` -- puts accumulator and counter back to zero for the next step.  No finalize launch.
+// FIN: the batch statistics arrive as fixed-point accumulators that the producing convolution's tiles added to (common.h fx_*); every
+// block finalises ALL channels once in its prologue, through LDS (the arithmetic of bn_finalize_kernel, so all blocks agree to the bit),
+// block 0 also writes mean / rstd / scale / shift for the backward pass, updates the running statistics and returns the layer's OTHER
+// accumulator to zero (`zero`: the one this launch reads is still being read by its other blocks).  No finalize launch.
 struct BnFwdAcc {
-    long long* acc;          // [2 words][2 sums][C]: the sums the producers added
+    long long* acc;          // [replicas][FX_WORDS][C]: the sums the producers added
     long long* zero;         // may be null: another accumulator of the same size that this launch returns to zero (the layer's other direction)
     int replicas;
     const float *gamma, *beta;
