@@ -179,7 +179,10 @@ class GraphedTrainStep:
                 self.targets[T:].zero_()
             self.targets[:T].copy_(targets, non_blocking=True)
         self.optimizer.sync_lr()
+        from . import ops
+        ops.settle_accumulators()                # the captured launches assume zero forward accumulators (ops._AccState)
         self.graph.replay()
+        ops.accumulators_after_replayed_step()
         self.replays += 1
         self.optimizer.note_replayed_steps(1)
         torch.autograd.graph.increment_version(self.params)          # eager code that follows must see the parameters as changed

@@ -9,6 +9,7 @@ zero-copy; foreign tensors (any strides, fp32/bf16) are packed on entry.
 """
 import ctypes as C
 import os
+import weakref
 import threading
 
 import torch
@@ -334,6 +335,7 @@ def flush_pending_apply():
 # and eval mode keep the table form / the running statistics; FVA_BN_ACC=0 selects the table form everywhere (what the accumulator form
 # is tested against, tests/test_gpu_bn_acc.py).
 _BN_ACC = [os.environ.get('FVA_BN_ACC', '1') != '0']
+_ACC_STATES = weakref.WeakSet()
 
 
 def set_bn_accumulators(on):
@@ -348,12 +350,13 @@ class _AccState:
     no clearing launch: each direction's consumer zeroes the other direction's accumulator.  ``replicas``: one copy per 65536 output
     pixels (a power of two, at most 32) -- the atomics on one address are served one after the other, ~10 ns each, and a layer at 320 x 320
     runs 12800 tiles."""
-    __slots__ = ('buf', 'state', 'replicas')
+    __slots__ = ('buf', 'state', 'replicas', '__weakref__')
 
     def __init__(self, Cc, M, device):
         self.replicas = _replicas(M)
         self.buf = torch.zeros((2, self.replicas * 5 * Cc), dtype=torch.int64, device=device)
         self.state = [0, 0]
+        _ACC_STATES.add(self)
 
     def produce(self, which):
         if self.state[which] != 0:          # left over from a pass whose other half never ran
@@ -365,6 +368,23 @@ class _AccState:
         self.state[1 - which] = 0           # the consumer returned the other direction's accumulator to zero
 
 
+def settle_accumulators():
+    """Bring every forward accumulator to zero whose sums nobody cleared (a training-mode forward pass whose backward never ran, an
+    aborted step).  Eager producers do this for themselves; a captured graph replays the launches of a NORMAL step and cannot look, so
+    graphs.GraphedTrainStep calls this before each replay (a host loop over the layers; a launch only for a dirty accumulator)."""
+    for st in list(_ACC_STATES):
+        if st.state[0] != 0:
+            st.buf[0].zero_()
+            st.state[0] = 0
+
+
+def accumulators_after_replayed_step():
+    """What a replayed step leaves behind on the device, noted on the host: forward accumulators zero (the backward consumers cleared
+    them), backward accumulators holding the step's sums (the next forward consumers clear them)."""
+    for st in list(_ACC_STATES):
+        st.state[0], st.state[1] = 0, 2
+
+
 def _replicas(M):
     r = 1
     while r < 32 and r * 65536 < M:
@@ -373,10 +393,19 @@ def _replicas(M):
 
 
 def _acc_state(gamma, M):
-    Cc = gamma.numel()
-    st = getattr(gamma, '_fva_acc', None)
-    if st is None or st.buf.device != gamma.device or st.replicas != _replicas(M) or st.buf.shape[1] != st.replicas * 5 * Cc:
-        st = gamma._fva_acc = _AccState(Cc, M, gamma.device)
+    """The layer's accumulators for a launch over M output pixels.  One _AccState per (device, replica count) is kept for as long as the
+    parameter lives -- never replaced: a captured graph holds the addresses of the one it was recorded with, and an eager step of another
+    batch size (another replica count) in between must not free it."""
+    Cc, R = gamma.numel(), _replicas(M)
+    cur = getattr(gamma, '_fva_acc', None)
+    if cur is not None and cur.replicas == R and cur.buf.device == gamma.device and cur.buf.shape[1] == R * 5 * Cc:
+        return cur
+    table = gamma.__dict__.setdefault('_fva_accs', {})
+    key = (gamma.device, R, Cc)
+    st = table.get(key)
+    if st is None:
+        st = table[key] = _AccState(Cc, M, gamma.device)
+    gamma._fva_acc = st
     return st
 
 
@@ -444,7 +473,7 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
         nblk = lib.fva_conv_stat_blocks(C.byref(d))
         mean = torch.empty_like(scale)
         rstd = torch.empty_like(scale)
-        if _BN_ACC[0] and gamma.is_cuda:
+        if _BN_ACC[0] and gamma.is_cuda and need_ctx:      # (a forward pass that no backward will follow keeps the table form: nobody would clear its sums)
             st = _acc_state(gamma, M)
             st.produce(0)
             fin = _Fin(st, gamma, beta, bn, mean, rstd, scale, shift)

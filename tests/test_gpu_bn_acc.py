@@ -267,3 +267,21 @@ def test_residual_chain_accumulators_vs_table(chans):
     for i, (u, v) in enumerate(zip(a, outs[False][0])):
         err = ((u.float() - v.float()).abs().max() / v.float().abs().max().clamp_min(1e-20)).item()
         assert err < 2e-2, (i, err)
+
+
+def test_accumulators_of_another_batch_size_do_not_replace_the_first_ones():
+    """A layer used at two sizes whose replica counts differ (here 65536-pixel threshold: 2 x 128 x 128 -> 1 copy, 8 x 128 x 128 -> 2) keeps
+    BOTH accumulator sets alive: a captured graph holds the addresses of the set it was recorded with."""
+    import fastvision_amd
+    from fastvision_amd import ops
+    conv, bn, _ = block((2, 32, 64, 128, 3, 1, torch.bfloat16))
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        ops.conv_bn_silu(torch.randn(2, 32, 128, 128, device=dev(), requires_grad=True), conv, bn)
+        small = bn.weight._fva_acc
+        ops.conv_bn_silu(torch.randn(8, 32, 128, 128, device=dev(), requires_grad=True), conv, bn)
+        big = bn.weight._fva_acc
+        ops.conv_bn_silu(torch.randn(2, 32, 128, 128, device=dev(), requires_grad=True), conv, bn)
+    torch.cuda.synchronize()
+    assert small.replicas == 1 and big.replicas == 2 and small is not big
+    assert bn.weight._fva_acc is small and small.buf.data_ptr() != big.buf.data_ptr()
+    assert set(bn.weight._fva_accs.values()) == {small, big}

@@ -205,3 +205,49 @@ def test_graphed_demo_step_is_bit_identical_with_eager():
         assert torch.equal(a, b), (a, b)
     for (k, a), (_, b) in zip(net2.state_dict().items(), net.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_replays_eager_steps_and_training_mode_forwards_interleave_like_eager():
+    """Round 4: the BatchNorm statistics live in per-layer accumulators whose zeroing is a protocol between launches (each direction's
+    consumer zeroes the other direction's accumulator; the host clears one only in front of a producer that finds it dirty).  A captured
+    graph replays the launches of a NORMAL step, so the protocol must also hold across the seams: replay -> eager step -> a training-mode
+    forward without backward (leaves forward sums behind) -> replay -> eager step.  The mixed sequence must equal the same steps issued
+    eagerly throughout, bit for bit."""
+    import fastvision_amd
+    from fastvision_amd.graphs import GraphedTrainStep
+    from fastvision_amd.synthetic import synthetic_batch
+    batches = [synthetic_batch(2, 128, seed=s) for s in (5, 6, 7)]
+    cap = max(t.shape[0] for _, t in batches) + 5
+    seq = ['g', 'e', 'f', 'g', 'e', 'g']             # g: graph replay, e: eager step, f: training-mode forward only (under no_grad)
+    pick = [0, 1, 2, 1, 0, 2]
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        net, crit, opt = make()
+        want = []
+        for kind, i in zip(seq, pick):
+            im, tg = batches[i]
+            if kind == 'f':
+                with torch.no_grad():
+                    net(im.to(DEV))                  # updates the running statistics, as nn.BatchNorm2d in training mode does
+            else:
+                want.append(eager_step(net, crit, opt, im.to(DEV), tg.to(DEV)))
+        want_state = state_of(net, opt)
+        torch.cuda.synchronize()
+
+        net2, crit2, opt2 = make()
+        step = GraphedTrainStep(net2, lambda p, t: crit2(p, t), opt2, batches[0][0].to(DEV), batches[0][1].to(DEV), max_targets=cap)
+        got = []
+        for kind, i in zip(seq, pick):
+            im, tg = batches[i]
+            if kind == 'g':
+                got.append(step(im.to(DEV), tg.to(DEV)).clone())
+            elif kind == 'e':
+                got.append(eager_step(net2, crit2, opt2, im.to(DEV), tg.to(DEV)))
+            else:
+                with torch.no_grad():
+                    net2(im.to(DEV))
+        got_state = state_of(net2, opt2)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), (a, b)
+    for k in want_state:
+        assert torch.equal(got_state[k], want_state[k]), k
