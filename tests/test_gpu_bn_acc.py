@@ -285,3 +285,53 @@ def test_accumulators_of_another_batch_size_do_not_replace_the_first_ones():
     assert small.replicas == 1 and big.replicas == 2 and small is not big
     assert bn.weight._fva_acc is small and small.buf.data_ptr() != big.buf.data_ptr()
     assert set(bn.weight._fva_accs.values()) == {small, big}
+
+
+def test_frozen_backbone_step_with_and_without_accumulators():
+    """Only the neck and the heads train (backbone parameters frozen: its blocks build no autograd state and keep the table form, the first
+    trainable block's backward has no producer to hand statistics to): two such steps with the accumulators on equal the table form to the
+    dtype's noise, repeat bit for bit, and leave every accumulator in its end-of-step state."""
+    import fastvision_amd
+    from fastvision_amd import ops
+    from fastvision_amd.classfication.models import darknet53
+    from fastvision_amd.detection.head import yolov3head
+    from fastvision_amd.detection.models import yolov3
+    from fastvision_amd.detection.neck import yolov3neck
+    from fastvision_amd.loss import Yolov3Loss
+    from fastvision_amd.synthetic import coco_anchors_px, synthetic_batch
+    images, tg = synthetic_batch(2, 128)
+    out = []
+    with fastvision_amd.compute_dtype(torch.bfloat16):
+        for on in (True, True, False):
+            prev = ops.set_bn_accumulators(on)
+            try:
+                torch.manual_seed(5)
+                net = yolov3(backbone=darknet53, neck=yolov3neck, head=yolov3head, anchors=coco_anchors_px(), num_anchors_per_level=[3, 3, 3],
+                             training=True).to(dev()).train()
+                for p in net.backbone.parameters():
+                    p.requires_grad_(False)
+                crit = Yolov3Loss(net, 0.5, 0.05, 1.0, 0.5)
+                losses = []
+                for _ in range(2):
+                    for p in net.parameters():
+                        p.grad = None
+                    loss = crit(net(images.to(dev())), tg.to(dev()))
+                    loss.backward()
+                    losses.append(loss.detach().clone())
+                torch.cuda.synchronize()
+                assert all(p.grad is None for p in net.backbone.parameters())
+                grads = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+                assert len(grads) > 40
+                out.append((losses, grads, [b.clone() for b in net.buffers()]))
+                if on:
+                    accs = [p._fva_acc for p in net.parameters() if hasattr(p, '_fva_acc')]
+                    assert 0 < len(accs) < 40, 'only the trainable blocks keep accumulators'
+                    assert all(a.state == [0, 2] and not a.buf[0].any() for a in accs)
+            finally:
+                ops.set_bn_accumulators(prev)
+    a, b, t = out
+    for u, v in zip(a[0] + a[1] + a[2], b[0] + b[1] + b[2]):
+        assert torch.equal(u, v)
+    assert abs(float(a[0][1]) - float(t[0][1])) <= 1e-4 * abs(float(t[0][1]))
+    worst = max(((u - v).abs().max() / v.abs().max().clamp_min(1e-20)).item() for u, v in zip(a[1], t[1]))
+    assert worst < 2e-2, worst
