@@ -610,7 +610,9 @@ def main():
                                    '(fwd + target assignment + yolov3_loss + bwd + grad all-reduce + Adam), COCO-80, random init',
                        'surface': args.surface, 'global_batch': args.batch * world, 'image_size': args.size,
                        'parallelism': f'dp{world}', 'wgrad_plan': fva_ops.get_wgrad_plan(),
-                       'host_env': {k: os.environ.get(k) for k in ('HSA_ENABLE_INTERRUPT', 'GPU_MAX_HW_QUEUES', 'FVA_WGRAD_STREAM', 'FVA_WGRAD_PLAN')
+                       'bn_statistics': 'accumulators' if fva_ops._BN_ACC[0] else 'tables', 'apply_fused_into_1x1': bool(fva_ops._DEFER['on']),
+                       'bn_backward_statistics_in_dgrad': bool(fva_ops._BN_FUSE[0]),
+                       'host_env': {k: os.environ.get(k) for k in ('HSA_ENABLE_INTERRUPT', 'GPU_MAX_HW_QUEUES', 'FVA_WGRAD_STREAM', 'FVA_WGRAD_PLAN', 'FVA_BN_ACC', 'FVA_FUSE_APPLY', 'FVA_BN_FUSE')
                                     if os.environ.get(k) is not None}},
             'roofline': {'bound': 'mfma', 'kernel': kernel_name, 'achieved': round(d['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(d['tflops'] / peak, 4), 'traffic': traffic,
