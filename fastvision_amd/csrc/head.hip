@@ -9,12 +9,18 @@ namespace {
 
 // dY (halo, Npad channels, zero beyond N and on the border) = g * dhead (dense fp32 rows of N = 255 floats: not 16-byte aligned).
 // One thread per 8 output channels: eight 4-byte loads (a wave covers whole cache lines of the row), one 16- or 32-byte store.
+// `partial` (may be null): the bias gradient's first stage rides along -- a thread keeps its 8-channel chunk for the whole grid-stride loop
+// (the chunks per pixel divide 256), adds up what it reads, and the block leaves partial[blockIdx][n] = the sum over its pixels: dhead is
+// read once instead of twice (the separate pass read 274 MB again at the very start of the backward pass, where nothing runs beside it).
 template <typename T>
 __global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restrict__ dhead, const float* __restrict__ gscale,
-                                                           T* __restrict__ dy, int B, int H, int W, int N, int Npad) {
+                                                           T* __restrict__ dy, int B, int H, int W, int N, int Npad, float* __restrict__ partial) {
     const uint32_t Hp = H + 2, Wp = W + 2, cpp = Npad / 8;
     const uint32_t total = (uint32_t)B * Hp * Wp * cpp;
     const float g = gscale ? *gscale : 1.f;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t pix = i / cpp, cc = i - pix * cpp;
         const uint32_t row = pix / Wp, xp = pix - row * Wp;
@@ -27,7 +33,11 @@ __global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restri
             const float* src = dhead + (((int64_t)b * H + y) * W + x) * N + cc * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if ((int)(cc * 8 + e) < N) v[e] = g * src[e];
+                if ((int)(cc * 8 + e) < N) {
+                    const float r = src[e];
+                    acc[e] += r;
+                    v[e] = g * r;
+                }
         }
         T* dst = dy + (int64_t)i * 8;
         if constexpr (sizeof(T) == 2) {
@@ -38,6 +48,19 @@ __global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restri
         } else {
             *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
             *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    }
+    if (partial != nullptr) {       // host: 256 % cpp == 0, so thread t owns chunk t % cpp throughout
+        __shared__ float red[256 * 8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+        __syncthreads();
+        const int groups = 256 / (int)cpp;
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const int cc = n >> 3, e = n & 7;
+            float t = 0.f;
+            for (int k = 0; k < groups; ++k) t += red[(k * (int)cpp + cc) * 8 + e];      // fixed order
+            partial[(int64_t)blockIdx.x * N + n] = t;
         }
     }
 }
@@ -85,20 +108,26 @@ extern "C" int fva_head_bwd_prepare(int dtype, const float* dhead, const float* 
     if (total >= (1ll << 31)) return fva_fail(FVA_ERR_ARG, "fva_head_bwd_prepare: tensor too large");
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
+    const int cpp = Npad / 8;
+    const bool ride = 256 % cpp == 0;           // the bias sums ride in the prepare pass (workspace: one row of N floats per block, <= 4096 rows)
+    float* part = (float*)workspace;
     if (dtype == FVA_BF16)
-        hipLaunchKernelGGL(head_prepare_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, dhead, grad_scale, (bf16_t*)dy, B, H, W, N, Npad);
+        hipLaunchKernelGGL(head_prepare_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, dhead, grad_scale, (bf16_t*)dy, B, H, W, N, Npad, ride ? part : nullptr);
     else if (dtype == FVA_F32)
-        hipLaunchKernelGGL(head_prepare_kernel<float>, dim3((int)g), dim3(256), 0, s, dhead, grad_scale, (float*)dy, B, H, W, N, Npad);
+        hipLaunchKernelGGL(head_prepare_kernel<float>, dim3((int)g), dim3(256), 0, s, dhead, grad_scale, (float*)dy, B, H, W, N, Npad, ride ? part : nullptr);
     else
         return fva_fail(FVA_ERR_ARG, "fva_head_bwd_prepare: bad dtype");
     FVA_LAUNCH_CHECK("head_prepare_kernel");
-    const int64_t M = (int64_t)B * H * W;
-    int nblocks = (int)((M + 63) / 64);
-    if (nblocks > 1024) nblocks = 1024;
-    const int rows = (int)((M + nblocks - 1) / nblocks);
-    nblocks = (int)((M + rows - 1) / rows);
-    hipLaunchKernelGGL(head_bias_partial_kernel, dim3(nblocks), dim3(256), 0, s, dhead, (float*)workspace, M, N, rows);
-    FVA_LAUNCH_CHECK("head_bias_partial_kernel");
+    int nblocks = (int)g;
+    if (!ride) {
+        const int64_t M = (int64_t)B * H * W;
+        nblocks = (int)((M + 63) / 64);
+        if (nblocks > 1024) nblocks = 1024;
+        const int rows = (int)((M + nblocks - 1) / nblocks);
+        nblocks = (int)((M + rows - 1) / rows);
+        hipLaunchKernelGGL(head_bias_partial_kernel, dim3(nblocks), dim3(256), 0, s, dhead, part, M, N, rows);
+        FVA_LAUNCH_CHECK("head_bias_partial_kernel");
+    }
     hipLaunchKernelGGL(head_bias_final_kernel, dim3(N), dim3(256), 0, s, (const float*)workspace, grad_scale, dbias, N,
                        nblocks, accumulate);
     FVA_LAUNCH_CHECK("head_bias_final_kernel");

@@ -985,7 +985,7 @@ class HeadFn(torch.autograd.Function):
             dout = dout.float().contiguous()
         dy = torch.empty((B, H + 2, W + 2, npad), dtype=dtype, device=dev)
         dbias = torch.empty(N, dtype=torch.float32, device=dev)
-        ws = torch.empty(1024 * N, dtype=torch.float32, device=dev)
+        ws = torch.empty(4096 * N, dtype=torch.float32, device=dev)
         _lib.call('fva_head_bwd_prepare', code, _p(dout), C.c_void_p(0), _p(dy), _p(dbias), 0, _p(ws), B, H, W, N, npad, _stream())
         # weight padded to npad rows so that dgrad / wgrad run as an ordinary Cout = npad convolution
         wpad = torch.zeros((npad, Cin, 1, 1), dtype=torch.float32, device=dev)

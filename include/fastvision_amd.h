@@ -211,7 +211,8 @@ int fva_stem_fused(int mode, const void* images_nhwc4, const float* w_oihw, cons
 int fva_head_fwd(const fva_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* out, void* stream);
 /* dhead fp32 [B*H*W][N] * (*grad_scale, device scalar, may be NULL = 1) -> dy (dtype) as a halo buffer
  * [B][H+2][W+2][Npad] (border 1, pad columns N..Npad-1 zero) ready for fva_conv_dgrad / fva_conv_wgrad with
- * Cout = Npad, and dbias[N] (+)= column sums (deterministic two-stage reduce; workspace >= 4*N*1024 bytes). */
+ * Cout = Npad, and dbias[N] (+)= column sums (deterministic two-stage reduce whose first stage rides in the pass that writes dy;
+ * workspace >= 4*N*4096 bytes). */
 int fva_head_bwd_prepare(int dtype, const float* dhead, const float* grad_scale, void* dy, float* dbias,
                          int accumulate, void* workspace, int B, int H, int W, int N, int Npad, void* stream);
 
