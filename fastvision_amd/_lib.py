@@ -138,6 +138,7 @@ PROTOTYPES = {
     'fva_yolov3_loss': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _P, _L, _P]),
     'fva_yolov3_loss_workspace': (_L, [_I, _H, _I]),
     'fva_yolov3_loss_dp': (_I, [_P, _I, _H, _I, _F, _F, _F, _P, _I, _P, _P, _L, _P]),
+    'fva_scale_by_device_scalar': (_I, [_P, _L, _P, _P]),
     'fva_bce_loss': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
     'fva_row_loss': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     'fva_smooth_l1': (_I, [_P, _P, _L, _P, _P, _P, _P]),

@@ -710,6 +710,20 @@ int check_level(const fva_head_level& l, const char* who) {
     return FVA_OK;
 }
 
+// x *= *scale, in place; every block leaves at once when the scalar is exactly 1 (the upstream gradient of loss.backward()): the loss
+// gradients then cost an empty launch instead of a 274 MB read-modify-write at the start of the backward pass
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ scale) {
+    const float s = *scale;
+    if (s == 1.f) return;
+    const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = *(f32x4*)(x + 4 * i);
+        v *= s;
+        *(f32x4*)(x + 4 * i) = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[n4 * 4 + threadIdx.x] *= s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -841,6 +855,17 @@ int fva_demo_loss(const float* targets, int32_t T, const fva_head_level* levels,
             FVA_LAUNCH_CHECK("demo_conf_kernel");
         }
     }
+    return FVA_OK;
+}
+
+int fva_scale_by_device_scalar(float* x, int64_t n, const float* scale, void* stream) {
+    if (!x || !scale || n < 0) return fva_fail(FVA_ERR_ARG, "fva_scale_by_device_scalar: bad argument");
+    if (n == 0) return FVA_OK;
+    int64_t g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+    FVA_LAUNCH_CHECK("scale_by_scalar_kernel");
     return FVA_OK;
 }
 

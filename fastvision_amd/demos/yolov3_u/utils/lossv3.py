@@ -56,14 +56,8 @@ class _DemoLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _gparts):
-        res = []
-        for g, dt in zip(ctx.grads, ctx.dtypes):
-            if g is None:
-                res.append(None)
-                continue
-            g = g * gout
-            res.append(g if g.dtype == dt else g.to(dt))
-        return (None, None, *res)
+        from ....ops import scale_loss_grads
+        return (None, None, *scale_loss_grads(ctx, gout))
 
 
 class ComputeLoss(nn.Module):

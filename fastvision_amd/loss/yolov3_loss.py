@@ -91,14 +91,8 @@ class _Yolov3LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _gparts):
-        res = []
-        for g, dt in zip(ctx.grads, ctx.dtypes):
-            if g is None:
-                res.append(None)
-                continue
-            g = g * gout            # scalar upstream gradient
-            res.append(g if g.dtype == dt else g.to(dt))
-        return (None, None, None, None, None, *res)
+        from ..ops import scale_loss_grads
+        return (None, None, None, None, None, *scale_loss_grads(ctx, gout))
 
 
 class Yolov3Loss(nn.Module):

@@ -533,6 +533,28 @@ def conv_block_fwd(x, x_ptr, x_pad, weight, gamma, beta, bn, training, stride, d
     return z, s
 
 
+def scale_loss_grads(ctx, gout):
+    """Chain rule of the fused losses (loss.Yolov3Loss, the demo's ComputeLoss): their forward pass already filled ctx.grads with
+    d loss / d head; backward multiplies by the upstream scalar.  For fp32 buffers that this package allocated the multiply runs IN
+    PLACE and is an empty launch when the scalar is exactly 1 (what ``loss.backward()`` passes): `g * gout` was a 274 MB
+    read-modify-write at the very start of the backward pass.  The buffers are spent afterwards: a second backward pass raises."""
+    grads, ctx.grads = ctx.grads, None
+    if grads is None:
+        raise _released('the loss')
+    res = []
+    for g, dt in zip(grads, ctx.dtypes):
+        if g is None:
+            res.append(None)
+            continue
+        if (gout.numel() == 1 and gout.dtype == torch.float32 and gout.is_cuda and g.is_cuda and g.dtype == torch.float32 and not gout.requires_grad
+                and g.storage_offset() == 0 and g.untyped_storage().nbytes() == g.numel() * 4 and g.data_ptr() % 16 == 0):
+            _lib.call('fva_scale_by_device_scalar', _p(g), g.numel(), _p(gout), _stream())
+        else:
+            g = g * gout
+        res.append(g if g.dtype == dt else g.to(dt))
+    return res
+
+
 # ---- weight gradients beside the rest of the backward pass ----------------------------------------------------------------
 # Nothing reads a layer's dW before the optimizer (or the gradient all-reduce), so the wgrad launches go to the library's
 # low-priority side stream: their blocks fill the CUs that the partly empty last round of the dgrad launches (800 / 400 / 200

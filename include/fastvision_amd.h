@@ -377,6 +377,11 @@ int fva_yolov3_loss_dp(const float* targets, int32_t T, const fva_head_level* le
                        float ratio_box, float ratio_conf, float ratio_cls, const int32_t* norm_counts, int32_t norm_batch,
                        float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* x[n] (fp32, 16-byte aligned) *= *scale (device scalar), in place; an empty launch when the scalar is exactly 1.  The chain rule of a
+ * loss whose gradient buffers were filled in its forward pass: autograd hands `loss.backward()` an upstream gradient of one, and the
+ * 3 x 91 MB multiply that `grad * gout` would be is what the backward pass starts with (loss/yolov3_loss.py:29-72 via autograd). */
+int fva_scale_by_device_scalar(float* x, int64_t n, const float* scale, void* stream);
+
 /* Stand-alone BiCrossEntropyLoss (loss/classification_loss.py:36-65) forward + dl/dy.  y [numel] fp32 logits (or probabilities:
  * already_sigmoid) seen as rows of C classes; target = one-hot of label[numel / C] (int64) or, label == NULL, the dense float
  * target [numel]; weights: NULL, one value, or numel values.  loss_out[1] = sum of the weighted element losses (/ numel when

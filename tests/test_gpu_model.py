@@ -822,3 +822,29 @@ def test_two_ranks_over_rccl():
     assert l0 == l1 and l0 >= nb - 2
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k
+
+
+def test_loss_gradients_follow_the_upstream_scalar_and_are_spent_by_backward(gold_lib, gold_demo):
+    """Round 4: the fused losses scale their stored head gradients by the upstream scalar in place (an empty launch for the 1 that
+    ``loss.backward()`` passes).  (loss * 0.5).backward() must give half the gradients of loss.backward() -- exactly: a power of two --
+    on both surfaces (to rounding), and a second backward pass through the same loss node raises instead of scaling twice."""
+    from fastvision_amd.demos.yolov3_u.utils import ComputeLoss
+
+    class M:
+        anchors = coco_anchors_feature()
+
+    def grads(scale, lossf, gold):
+        hs = [T(gold[f'g3_syn_head{l}']).to(DEV).requires_grad_(True) for l in range(3)]
+        loss = lossf(hs, T(gold['g3_syn_targets']).to(DEV))
+        (loss * scale).backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match='already been released'):
+            loss.backward()
+        return [h.grad.clone() for h in hs]
+
+    crit, cl = lib_loss(), ComputeLoss()
+    for lossf, gold in ((lambda hs, tg: crit(hs, tg), gold_lib), (lambda hs, tg: cl(hs, tg, M()), gold_demo)):
+        full, half = grads(1.0, lossf, gold), grads(0.5, lossf, gold)
+        for a, b in zip(full, half):
+            # (two forward passes: the loss kernels' few fp32 atomics may land in another order, so equal to rounding, not bit for bit)
+            assert a.abs().max() > 0 and torch.allclose(a * 0.5, b, rtol=1e-5, atol=1e-9)
+            assert not torch.allclose(a, b, rtol=1e-2, atol=0)
